@@ -1,0 +1,312 @@
+/*
+ * toyni_oracle.c -- CPU restatement of the reference's BabyBear NTT / FRI-fold path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under toyni_amd/ may link, import or call this
+ * file.  It is used by tests/, by __graft_entry__.smoke() as the checker, and by
+ * bench.py's `cpu_baseline` leg ("kind": "port", 1 thread) -- never as the thing shipped.
+ *
+ * Parity status: PINNED.  The reference (Rust + CUDA) cannot be compiled in this image
+ * (no cargo/rustc/nvcc -- SURVEY.md F6), so the pin is (a) every known-answer test the
+ * reference's own test-suite holds for this path (src/ntt.rs:321-379, src/babybear.rs:219-284,
+ * src/math/domain.rs:192-242) re-run against this file in tests/test_oracle.py, and (b) golden
+ * vectors produced by an independent big-integer O(n^2) DFT model (tests/golden/gen_golden.py).
+ *
+ * Every function cites the reference file:line it restates.  The loop structure follows the
+ * reference on purpose (same algorithm => meaningful CPU timing baseline): multiplication is
+ * `unsigned __int128 %` exactly as src/babybear.rs:173-176.
+ *
+ * Element layout: one uint64_t per field element, canonical residue in [0,p)
+ * (#[repr(C)] struct BabyBear { value: u64 } -- src/babybear.rs:10-14).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BB_P 2013265921ULL /* src/babybear.rs:8  p = 2^31 - 2^27 + 1 */
+
+/* src/babybear.rs:26-30  BabyBear::new */
+uint64_t orc_bb_new(uint64_t v) { return v % BB_P; }
+
+/* src/babybear.rs:80-89 reduce_wide + :129-139 Add */
+uint64_t orc_bb_add(uint64_t a, uint64_t b) {
+    uint64_t v = a + b;
+    if (v >= BB_P) v -= BB_P;
+    if (v >= BB_P) v -= BB_P;
+    return v;
+}
+
+/* src/babybear.rs:148-160 Sub */
+uint64_t orc_bb_sub(uint64_t a, uint64_t b) {
+    return a >= b ? a - b : a + BB_P - b;
+}
+
+/* src/babybear.rs:169-178 Mul: (a as u128 * b as u128) % p */
+uint64_t orc_bb_mul(uint64_t a, uint64_t b) {
+    unsigned __int128 prod = (unsigned __int128)a * (unsigned __int128)b;
+    return (uint64_t)(prod % (unsigned __int128)BB_P);
+}
+
+/* src/babybear.rs:195-207 Neg */
+uint64_t orc_bb_neg(uint64_t a) { return a == 0 ? 0 : BB_P - a; }
+
+/* src/babybear.rs:91-108 pow (square-and-multiply, LSB first) */
+uint64_t orc_bb_pow(uint64_t base, uint64_t exp) {
+    if (exp == 0) return 1;
+    uint64_t result = 1;
+    while (exp > 0) {
+        if (exp & 1) result = orc_bb_mul(result, base);
+        base = orc_bb_mul(base, base);
+        exp >>= 1;
+    }
+    return result;
+}
+
+/* src/babybear.rs:111-114 inverse = a^(p-2); caller guarantees a != 0 (reference asserts) */
+uint64_t orc_bb_inverse(uint64_t a) { return orc_bb_pow(a, BB_P - 2); }
+
+/* src/babybear.rs:187-193 Div */
+uint64_t orc_bb_div(uint64_t a, uint64_t b) { return orc_bb_mul(a, orc_bb_inverse(b)); }
+
+/* src/babybear.rs:118-126 get_root_of_unity: 440564289^(2^(27-log_n)); log_n <= 27.
+ * Returns 0 for log_n > 27 (the reference panics). */
+uint64_t orc_bb_root_of_unity(uint32_t log_n) {
+    if (log_n > 27) return 0;
+    return orc_bb_pow(orc_bb_new(440564289ULL), 1ULL << (27 - log_n));
+}
+
+/* src/ntt.rs:14-21 bit_reverse */
+static size_t orc_bit_reverse(size_t x, unsigned log_n) {
+    size_t r = 0;
+    for (unsigned i = 0; i < log_n; ++i) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+static unsigned orc_log2(size_t n) {
+    unsigned l = 0;
+    while (((size_t)1 << l) < n) ++l;
+    return l;
+}
+
+/* src/ntt.rs:24-53 ntt: in-place radix-2 DIT Cooley-Tukey, natural order in and out.
+ * Returns -1 if n is not a power of two (the reference asserts). */
+int orc_ntt(uint64_t *values, size_t n, uint64_t omega) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    unsigned log_n = orc_log2(n);
+
+    for (size_t i = 0; i < n; ++i) {          /* :29-34 */
+        size_t j = orc_bit_reverse(i, log_n);
+        if (i < j) {
+            uint64_t t = values[i];
+            values[i] = values[j];
+            values[j] = t;
+        }
+    }
+
+    for (size_t len = 2; len <= n; len *= 2) { /* :36-52 */
+        size_t step = n / len;
+        uint64_t w_len = orc_bb_pow(omega, (uint64_t)step);
+        for (size_t i = 0; i < n; i += len) {
+            uint64_t w = 1;
+            for (size_t j = 0; j < len / 2; ++j) {
+                uint64_t u = values[i + j];
+                uint64_t v = orc_bb_mul(values[i + j + len / 2], w);
+                values[i + j] = orc_bb_add(u, v);
+                values[i + j + len / 2] = orc_bb_sub(u, v);
+                w = orc_bb_mul(w, w_len);
+            }
+        }
+    }
+    return 0;
+}
+
+/* src/ntt.rs:56-66 intt: ntt with omega^(n-1), then every element * n^-1 */
+int orc_intt(uint64_t *values, size_t n, uint64_t omega) {
+    uint64_t inv_omega = orc_bb_pow(omega, (uint64_t)n - 1);
+    int rc = orc_ntt(values, n, inv_omega);
+    if (rc) return rc;
+    uint64_t inv_n = orc_bb_inverse(orc_bb_new((uint64_t)n));
+    for (size_t i = 0; i < n; ++i) values[i] = orc_bb_mul(values[i], inv_n);
+    return 0;
+}
+
+/* What src/ntt.rs:224-251 (ntt_cuda / intt_cuda) compute: the transform with the canonical
+ * root get_root_of_unity(log2 n) -- they take no omega argument. */
+int orc_ntt_canonical(uint64_t *values, size_t n) {
+    if (n == 0 || (n & (n - 1)) || orc_log2(n) > 27) return -1;
+    return orc_ntt(values, n, orc_bb_root_of_unity(orc_log2(n)));
+}
+int orc_intt_canonical(uint64_t *values, size_t n) {
+    if (n == 0 || (n & (n - 1)) || orc_log2(n) > 27) return -1;
+    return orc_intt(values, n, orc_bb_root_of_unity(orc_log2(n)));
+}
+
+/* src/ntt.rs:69-81 roots_of_unity_domain */
+int orc_roots_of_unity_domain(uint64_t *out, size_t n) {
+    if (n == 0 || (n & (n - 1)) || orc_log2(n) > 27) return -1;
+    uint64_t omega = orc_bb_root_of_unity(orc_log2(n));
+    uint64_t cur = 1;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = cur;
+        cur = orc_bb_mul(cur, omega);
+    }
+    return 0;
+}
+
+/* src/math/domain.rs:61-69 BabyBearDomain::elements: shift * omega^i */
+int orc_domain_elements(uint64_t *out, size_t n, uint64_t shift) {
+    if (n == 0 || (n & (n - 1)) || orc_log2(n) > 27) return -1;
+    uint64_t omega = orc_bb_root_of_unity(orc_log2(n));
+    uint64_t cur = shift;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = cur;
+        cur = orc_bb_mul(cur, omega);
+    }
+    return 0;
+}
+
+/* src/math/domain.rs:154-162 apply_coset_shift: values[i] *= shift^i (skipped when shift == 1) */
+static void orc_apply_coset_shift(uint64_t *v, size_t n, uint64_t shift) {
+    if (shift != 1) {
+        uint64_t sp = 1;
+        for (size_t i = 0; i < n; ++i) {
+            v[i] = orc_bb_mul(v[i], sp);
+            sp = orc_bb_mul(sp, shift);
+        }
+    }
+}
+
+/* src/math/domain.rs:165-174 undo_coset_shift: values[i] *= shift^-i */
+static void orc_undo_coset_shift(uint64_t *v, size_t n, uint64_t shift) {
+    if (shift != 1) {
+        uint64_t sinv = orc_bb_inverse(shift);
+        uint64_t sp = 1;
+        for (size_t i = 0; i < n; ++i) {
+            v[i] = orc_bb_mul(v[i], sp);
+            sp = orc_bb_mul(sp, sinv);
+        }
+    }
+}
+
+/* src/math/domain.rs:107-123 BabyBearDomain::fft: zero-pad coeffs to `size`, coset pre-scale, NTT.
+ * `out` has `size` elements; ncoeffs <= size. */
+int orc_domain_fft(uint64_t *out, size_t size, const uint64_t *coeffs, size_t ncoeffs, uint64_t shift) {
+    if (ncoeffs > size) return -1;
+    memcpy(out, coeffs, ncoeffs * sizeof(uint64_t));
+    memset(out + ncoeffs, 0, (size - ncoeffs) * sizeof(uint64_t));
+    orc_apply_coset_shift(out, size, shift);
+    return orc_ntt_canonical(out, size);
+}
+
+/* src/math/domain.rs:85-102 BabyBearDomain::ifft: INTT then coset post-scale. In place on `values`. */
+int orc_domain_ifft(uint64_t *values, size_t size, uint64_t shift) {
+    int rc = orc_intt_canonical(values, size);
+    if (rc) return rc;
+    orc_undo_coset_shift(values, size, shift);
+    return 0;
+}
+
+/* src/math/fri.rs:27-48 fri_fold: out[i] = (a+b)/2 + (a-b)/2 * beta / xs[i],
+ * a = evals[i], b = evals[i+half]; only xs[0..half) is read.  One Fermat inversion per element
+ * exactly as the reference (x.inverse() at :42).  Returns -1 on odd length (reference asserts). */
+int orc_fri_fold(uint64_t *out, const uint64_t *evals, size_t len, const uint64_t *xs, uint64_t beta) {
+    if (len % 2) return -1;
+    size_t half = len / 2;
+    uint64_t half_inv = orc_bb_inverse(orc_bb_new(2));
+    for (size_t i = 0; i < half; ++i) {
+        uint64_t a = evals[i];
+        uint64_t b = evals[i + half];
+        uint64_t x = xs[i];
+        uint64_t avg = orc_bb_mul(orc_bb_add(a, b), half_inv);
+        uint64_t diff = orc_bb_mul(orc_bb_sub(a, b), half_inv);
+        /* avg + diff * beta * x.inverse()  -- left-to-right as written at :42 */
+        out[i] = orc_bb_add(avg, orc_bb_mul(orc_bb_mul(diff, beta), orc_bb_inverse(x)));
+    }
+    return 0;
+}
+
+/* The prover's use of fri_fold (src/fibonacci.rs:214,220-245): layer 0 points are the coset
+ * elements shift*omega_N^i; after each fold xs is truncated to the folded length and squared.
+ * This helper reproduces that loop for `nfolds` layers on a codeword of size N and writes every
+ * folded layer back to back into `layers_out` (sizes N/2, N/4, ...).  betas[k] is the challenge
+ * of fold k. */
+int orc_fri_fold_layers(uint64_t *layers_out, const uint64_t *evals, size_t N, uint64_t shift,
+                        const uint64_t *betas, unsigned nfolds) {
+    if (N == 0 || (N & (N - 1))) return -1;
+    uint64_t *xs = (uint64_t *)malloc(N * sizeof(uint64_t));
+    uint64_t *cur = (uint64_t *)malloc(N * sizeof(uint64_t));
+    if (!xs || !cur) { free(xs); free(cur); return -2; }
+    orc_domain_elements(xs, N, shift);
+    memcpy(cur, evals, N * sizeof(uint64_t));
+    size_t len = N;
+    uint64_t *dst = layers_out;
+    for (unsigned k = 0; k < nfolds && len >= 2; ++k) {
+        orc_fri_fold(dst, cur, len, xs, betas[k]);
+        size_t half = len / 2;
+        for (size_t i = 0; i < half; ++i) xs[i] = orc_bb_mul(xs[i], xs[i]); /* :228-231 */
+        memcpy(cur, dst, half * sizeof(uint64_t));
+        dst += half;
+        len = half;
+    }
+    free(xs);
+    free(cur);
+    return 0;
+}
+
+/* ---- Ext = F_p[X]/(X^4 - 11), src/ext.rs -- only what fri_fold_ext needs (row a20, "next") ---- */
+
+/* src/ext.rs:178-192 schoolbook multiply with X^4 = 11 */
+static void orc_ext_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            t[i + j] = orc_bb_add(t[i + j], orc_bb_mul(a[i], b[j]));
+    for (int k = 0; k < 4; ++k) {
+        uint64_t v = t[k];
+        if (k + 4 < 7) v = orc_bb_add(v, orc_bb_mul(t[k + 4], 11));
+        r[k] = v;
+    }
+}
+
+/* src/math/fri.rs:7-25 fri_fold_ext: Ext values and beta, base-field xs. evals/out are AoS 4xu64. */
+int orc_fri_fold_ext(uint64_t *out, const uint64_t *evals, size_t len, const uint64_t *xs, const uint64_t beta[4]) {
+    if (len % 2) return -1;
+    size_t half = len / 2;
+    uint64_t half_inv = orc_bb_inverse(orc_bb_new(2));
+    for (size_t i = 0; i < half; ++i) {
+        const uint64_t *a = evals + 4 * i;
+        const uint64_t *b = evals + 4 * (i + half);
+        uint64_t x_inv = orc_bb_inverse(xs[i]);
+        uint64_t avg[4], diff[4], db[4], xe[4] = {x_inv, 0, 0, 0}, prod[4];
+        for (int k = 0; k < 4; ++k) {
+            avg[k] = orc_bb_mul(orc_bb_add(a[k], b[k]), half_inv);
+            diff[k] = orc_bb_mul(orc_bb_sub(a[k], b[k]), half_inv);
+        }
+        orc_ext_mul(db, diff, beta);   /* diff * beta */
+        orc_ext_mul(prod, db, xe);     /* * Ext::from_base(x_inv) */
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = orc_bb_add(avg[k], prod[k]);
+    }
+    return 0;
+}
+
+/* ---- synthetic inputs shared by tests and bench ---- */
+
+/* I1: x[i] = (7*i + 3) mod p -- the reference's own test pattern, src/ntt.rs:272 */
+void orc_fill_pattern_7i3(uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_bb_new((uint64_t)i * 7 + 3);
+}
+
+static uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+/* I2: x[i] = splitmix64(seed + i) mod p */
+void orc_fill_splitmix(uint64_t *out, size_t n, uint64_t seed) {
+    for (size_t i = 0; i < n; ++i) out[i] = orc_splitmix64(seed + (uint64_t)i) % BB_P;
+}

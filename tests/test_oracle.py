@@ -1,0 +1,191 @@
+"""Pins oracle/toyni_oracle.c (the CPU restatement) against
+ (a) every known-answer test the reference holds for this path, restated from
+     /root/reference/src/{babybear,ntt}.rs and src/math/domain.rs test modules, and
+ (b) the independent big-int golden vectors in tests/golden/vectors.json.
+CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+
+
+# ---- src/babybear.rs:219-284 ----
+def test_basic_arithmetic():
+    assert oracle.bb_add(100, 200) == 300
+    assert oracle.bb_sub(200, 100) == 100
+    assert oracle.bb_mul(100, 200) == 20000
+
+
+def test_modular_reduction():
+    assert oracle.bb_new(P + 5) == 5
+
+
+def test_inverse():
+    assert oracle.bb_mul(7, oracle.bb_inverse(7)) == 1
+
+
+def test_pow():
+    assert oracle.bb_pow(3, 4) == 81
+
+
+def test_root_of_unity():
+    for log_n in range(1, 11):
+        assert oracle.bb_pow(oracle.root_of_unity(log_n), 1 << log_n) == 1
+
+
+def test_negation():
+    assert oracle.bb_add(100, oracle.bb_neg(100)) == 0
+    assert oracle.bb_neg(0) == 0
+
+
+def test_division():
+    q = oracle.bb_div(100, 7)
+    assert oracle.bb_mul(q, 7) == 100
+
+
+def test_field_golden(golden):
+    g = golden["field"]
+    assert oracle.bb_inverse(7) == g["inv_7"]
+    assert oracle.bb_neg(100) == g["neg_100"]
+    assert oracle.bb_div(100, 7) == g["div_100_7"]
+    assert oracle.bb_inverse(2) == g["half_inv"]
+    assert oracle.bb_mul(P - 1, P - 1) == g["mul_pm1_pm1"]
+    assert [oracle.root_of_unity(k) for k in range(28)] == golden["roots_of_unity"]
+
+
+def test_sub_wraps_and_add_reduces():
+    assert oracle.bb_sub(0, 1) == P - 1
+    assert oracle.bb_add(P - 1, P - 1) == P - 2
+    rng = np.random.default_rng(1)
+    for a, b in rng.integers(0, P, size=(200, 2)):
+        a, b = int(a), int(b)
+        assert oracle.bb_mul(a, b) == a * b % P
+        assert oracle.bb_add(a, b) == (a + b) % P
+        assert oracle.bb_sub(a, b) == (a - b) % P
+
+
+# ---- src/ntt.rs:321-379 ----
+def test_ntt_intt_roundtrip():
+    n = 256
+    omega = oracle.root_of_unity(8)
+    values = oracle.pattern_7i3(n)
+    out = oracle.intt(oracle.ntt(values, omega), omega)
+    assert (out == values).all()
+
+
+def test_polynomial_evaluation():
+    n = 8
+    omega = oracle.root_of_unity(3)
+    domain = oracle.roots_of_unity_domain(n)
+    coeffs = [1, 2, 3, 0, 0, 0, 0, 0]
+    evals = oracle.ntt(coeffs, omega)
+    assert evals[0] == 6
+    x = int(domain[1])
+    assert evals[1] == (1 + 2 * x + 3 * x * x) % P
+
+
+def test_roots_of_unity():
+    n = 16
+    domain = oracle.roots_of_unity_domain(n)
+    assert domain[0] == 1
+    assert oracle.bb_pow(int(domain[1]), n) == 1
+    assert len(set(domain.tolist())) == n
+
+
+def test_ntt_golden(golden):
+    for c in golden["ntt"]:
+        fwd = oracle.ntt(c["input"], c["omega"])
+        assert fwd.tolist() == c["forward"], c["name"]
+        assert oracle.ntt(c["input"]).tolist() == c["forward"], c["name"]  # canonical root
+        inv = oracle.intt(c["input"], c["omega"])
+        assert inv.tolist() == c["inverse"], c["name"]
+
+
+def test_ntt_rejects_non_pow2():
+    with pytest.raises(AssertionError):
+        oracle.ntt([1, 2, 3])
+
+
+# ---- src/math/domain.rs:192-242 ----
+def test_fft_ifft_roundtrip():
+    coeffs = [(i * 3 + 1) % P for i in range(8)]
+    assert oracle.domain_ifft(oracle.domain_fft(coeffs, 8)).tolist() == coeffs
+
+
+def test_coset_fft_ifft_roundtrip():
+    coeffs = [(i * 3 + 1) % P for i in range(8)]
+    assert oracle.domain_ifft(oracle.domain_fft(coeffs, 8, 7), 7).tolist() == coeffs
+
+
+def test_coset_golden(golden):
+    for c in golden["coset"]:
+        assert oracle.domain_elements(c["size"], c["shift"]).tolist() == c["points"], c["name"]
+        evals = oracle.domain_fft(c["coeffs"], c["size"], c["shift"])
+        assert evals.tolist() == c["evals"], c["name"]
+        back = oracle.domain_ifft(evals, c["shift"]).tolist()
+        assert back[: len(c["coeffs"])] == c["coeffs"] and not any(back[len(c["coeffs"]):])
+
+
+# ---- src/math/fri.rs:27-48 ----
+def test_fold_golden(golden):
+    for c in golden["fold"]:
+        assert oracle.fri_fold(c["evals"], c["xs"], c["beta"]).tolist() == c["folded"], c["name"]
+        # only xs[0..half) is read (src/math/fri.rs:36)
+        assert oracle.fri_fold(c["evals"], c["xs"][: c["n"] // 2], c["beta"]).tolist() == c["folded"]
+
+
+def test_fold_layers_golden(golden):
+    c = golden["fold_layers"]
+    layers = oracle.fri_fold_layers(c["evals"], c["shift"], c["betas"])
+    assert [l.tolist() for l in layers] == c["layers"]
+    assert len(set(layers[-1].tolist())) == 1  # src/verifier.rs:69-75
+
+
+def test_fold_matches_verifier_restatement():
+    # src/verifier.rs:177-181: avg + diff * beta * x0.inverse()
+    n = 64
+    evals = oracle.splitmix(n, 5)
+    xs = oracle.domain_elements(n, 7)
+    beta = 987654321
+    out = oracle.fri_fold(evals, xs, beta)
+    half_inv = pow(2, P - 2, P)
+    for i in range(n // 2):
+        a, b, x = int(evals[i]), int(evals[i + n // 2]), int(xs[i])
+        exp = ((a + b) * half_inv + (a - b) * half_inv * beta * pow(x, P - 2, P)) % P
+        assert out[i] == exp
+
+
+def test_fold_rejects_odd():
+    with pytest.raises(AssertionError):
+        oracle.fri_fold([1, 2, 3], [1, 2, 3], 5)
+
+
+def test_fold_ext_embeds_base():
+    # a base-field codeword embedded in Ext with a base beta folds to the embedded base fold
+    n = 32
+    evals = oracle.splitmix(n, 9)
+    xs = oracle.domain_elements(n, 7)
+    beta = 424242
+    base = oracle.fri_fold(evals, xs, beta)
+    e4 = np.zeros((n, 4), dtype=np.uint64)
+    e4[:, 0] = evals
+    out = oracle.fri_fold_ext(e4, xs, [beta, 0, 0, 0])
+    assert (out[:, 0] == base).all() and not out[:, 1:].any()
+
+
+def test_fold_ext_is_coordinatewise_linear_with_x4_eq_11():
+    # beta = X: (d0 + d1 X + d2 X^2 + d3 X^3) * X = 11 d3 + d0 X + d1 X^2 + d2 X^3  (src/ext.rs:178-192)
+    n = 8
+    rng = np.random.default_rng(3)
+    e4 = rng.integers(0, P, size=(n, 4)).astype(np.uint64)
+    xs = oracle.domain_elements(n, 7)
+    out = oracle.fri_fold_ext(e4, xs, [0, 1, 0, 0])
+    hi = pow(2, P - 2, P)
+    for i in range(n // 2):
+        a, b = [int(v) for v in e4[i]], [int(v) for v in e4[i + n // 2]]
+        xinv = pow(int(xs[i]), P - 2, P)
+        avg = [(x + y) * hi % P for x, y in zip(a, b)]
+        d = [(x - y) * hi % P for x, y in zip(a, b)]
+        dx = [11 * d[3] % P, d[0], d[1], d[2]]
+        assert out[i].tolist() == [(avg[k] + dx[k] * xinv) % P for k in range(4)]
