@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- BabyBear NTT throughput on MI355X (BASELINE.json metric).
+
+A *step* is one pass of the hot path over one batch of synthetic input resident in HBM: every transform
+of the per-GPU batch is taken forward and back (forward NTT + inverse NTT, BASELINE configs[1]) at
+n = 2^20; the batch is the repeated-prover workload of configs[3] (1024 transforms per GPU, sharded over
+ranks with no collective -- weak scaling).  value = transforms * n / seconds, whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--batch 1024]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  torch is plumbing here (device memory, streams, torch.distributed); the
+compute is libtoyni_hip.so through the C ABI.  The oracle is used only for the cpu_baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P = 2013265921
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU (weak scaling)")
+    ap.add_argument("--chunk-elems", type=int, default=-1, help="override the context's batch chunking (-1: library default)")
+    ap.add_argument("--no-extras", action="store_true", help="skip single-transform / fold / host-path side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--microbench", action="store_true", help="also print integer-multiply issue rates (stderr)")
+    return ap.parse_args()
+
+
+def cpu_baseline(log_n, seconds):
+    """The oracle (C restatement of src/ntt.rs:24-66, u128 % multiply) on one host core: forward + inverse at n."""
+    import numpy as np
+    import oracle
+    n = 1 << log_n
+    x = oracle.splitmix(n, 0xB45E)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        y = oracle.ntt(x)
+        x2 = oracle.intt(y)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 200:
+            break
+    assert (x2 == x).all()
+    return {
+        "value": 2 * reps * n / el, "unit": "elements/s", "cores": 1, "kind": "port",
+        "sample": f"{reps} x (forward + inverse) NTT n=2^{log_n} on 1 thread, {el:.1f} s; oracle/toyni_oracle.c "
+                  f"(reference algorithm src/ntt.rs:24-66; the Rust reference itself cannot be built here)",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build_hip()
+    if distributed:
+        dist.barrier()
+    import toyni_amd
+
+    n = 1 << args.log_n
+    batch = args.batch
+    ctx = toyni_amd.NttContext(n, device=dev.index)
+    if args.chunk_elems >= 0:
+        ctx.set_chunk(args.chunk_elems)
+
+    # synthetic batch: uniform residues, a different seed per rank (never zeros: clocks rise on trivial operands)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x70796E69 + rank)
+    data = torch.empty(batch * n, dtype=torch.int32, device=dev)
+    piece = 1 << 26
+    for off in range(0, batch * n, piece):
+        m = min(piece, batch * n - off)
+        data[off:off + m] = torch.randint(0, P, (m,), dtype=torch.int32, device=dev, generator=gen)
+    check_before = data[: n].clone()
+    stream = torch.cuda.current_stream().cuda_stream
+    ptr = data.data_ptr()
+
+    def step():
+        ctx.run_device(ptr, ptr, batch, False, stream=stream)
+        ctx.run_device(ptr, ptr, batch, True, stream=stream)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    gpu_s = ev0.elapsed_time(ev1) / 1e3
+    # forward + inverse leaves the batch unchanged: a free end-to-end sanity check of the timed region
+    assert torch.equal(data[: n], check_before), "round trip changed the data"
+
+    el = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    wall_max = float(el.item())
+    transforms = 2 * batch * args.steps * world
+    value = transforms * n / wall_max
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "BabyBear NTT throughput (forward+inverse, device-resident)", "value": value, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over a batch of {batch} transforms per GPU "
+                            f"(configs[3] repeated-prover batch), in place, inputs resident in HBM",
+                "log_n": args.log_n, "batch_per_gpu": batch, "passes_per_transform": ctx.passes,
+                "parallelism": f"batch-sharded x{world}, no collective",
+            },
+            "gpu_event_ms_per_step": gpu_s / args.steps * 1e3,
+        }
+
+    # ---- roofline of the dominant kernel: per-pass launch durations, HIP events on the launch stream ----
+    if rank == 0:
+        fwd_ms = ctx.profile_passes(ptr, batch, False, reps=10, stream=stream)
+        inv_ms = ctx.profile_passes(ptr, batch, True, reps=10, stream=stream)
+        npass = ctx.passes
+        dom = max(range(npass), key=lambda p: fwd_ms[p])
+        # algorithmic bytes: 8 B per element per transform; one launch is one of `npass` sweeps of the
+        # batch, so its share is 8 * n * batch / npass.
+        alg_bytes = 8.0 * n * batch / npass
+        achieved = alg_bytes / (fwd_ms[dom] * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": f"ntt_pass_kernel pass {dom} of {npass} (forward)", "kernel_ms": fwd_ms[dom],
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "all_pass_ms": {"forward": fwd_ms, "inverse": inv_ms},
+            "kernel_stream_GBps": 8.0 * n * batch / (fwd_ms[dom] * 1e-3) / 1e9,
+            "transform_algorithmic_GBps": 8.0 * n * batch / (sum(fwd_ms) * 1e-3) / 1e9,
+        }
+
+    # ---- side measurements (not `value`) ----
+    if rank == 0 and not args.no_extras:
+        extras = {}
+
+        def time_dev(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e-3
+
+        for ln in (20, 24):
+            nn = 1 << ln
+            c1 = toyni_amd.NttContext(nn, device=dev.index)
+            buf = torch.randint(0, P, (nn,), dtype=torch.int32, device=dev)
+            p1 = buf.data_ptr()
+            t_f = time_dev(lambda: c1.run_device(p1, p1, 1, False, stream=stream), 50)
+            t_i = time_dev(lambda: c1.run_device(p1, p1, 1, True, stream=stream), 50)
+            extras[f"single_n2^{ln}"] = {
+                "forward_us": t_f * 1e6, "inverse_us": t_i * 1e6, "forward_elements_per_s": nn / t_f,
+                "frac_of_1e12_ceiling": nn / t_f / 1e12, "note": "one transform, kernel-only, working set cache-resident",
+            }
+            if ln == 24:
+                # FRI fold GB/s on the 2^24 layer: algorithmic 6 B per input element
+                o = torch.empty(nn // 2, dtype=torch.int32, device=dev)
+                t_fold = time_dev(lambda: toyni_amd.fri_fold_device(c1, p1, o.data_ptr(), nn, 123456789, 7, stream=stream), 50)
+                extras["fri_fold_m2^24"] = {"us": t_fold * 1e6, "GBps": 6.0 * nn / t_fold / 1e9, "frac_of_hbm_peak": 6.0 * nn / t_fold / 1e9 / HBM_PEAK_GBPS}
+                big = torch.randint(0, P, (1 << 28,), dtype=torch.int32, device=dev)  # 1 GiB layer: beyond the Infinity Cache
+                c27 = toyni_amd.NttContext(1 << 27, device=dev.index)
+                o2 = torch.empty(1 << 26, dtype=torch.int32, device=dev)
+                t_fold = time_dev(lambda: toyni_amd.fri_fold_device(c27, big.data_ptr(), o2.data_ptr(), 1 << 27, 123456789, 7, stream=stream), 20)
+                extras["fri_fold_m2^27"] = {"us": t_fold * 1e6, "GBps": 6.0 * (1 << 27) / t_fold / 1e9, "frac_of_hbm_peak": 6.0 * (1 << 27) / t_fold / 1e9 / HBM_PEAK_GBPS}
+                del big, o2
+                c27.destroy()
+            # reference-shaped host-slice entry point (PCIe inclusive; never `value`)
+            h = np.random.default_rng(1).integers(0, P, nn, dtype=np.uint64)
+            c1.run_host(h, False)
+            t0h = time.perf_counter()
+            reps_h = 5
+            for _ in range(reps_h):
+                c1.run_host(h, False)
+            th = (time.perf_counter() - t0h) / reps_h
+            extras[f"host_slice_n2^{ln}"] = {"ms": th * 1e3, "elements_per_s": nn / th, "note": "ntt_cuda-shaped call: H2D u64 + kernels + D2H u64, pageable host memory"}
+            c1.destroy()
+        out["extras"] = extras
+
+    if rank == 0 and args.microbench:
+        import ctypes
+        names = ["mont_mul", "barrett64", "add+sub", "mul_lo_u32", "mul_hi_u32", "mad_u64_u32"]
+        for which, nm in enumerate(names):
+            ms, sink = ctypes.c_float(0), ctypes.c_uint32(0)
+            iters, blocks = 4096, 256 * 8
+            toyni_amd._lib.check(toyni_amd._lib.lib.toyni_microbench(which, iters, blocks, ctypes.byref(ms), ctypes.byref(sink)), "microbench")
+            ops = iters * 8.0 * blocks * 256
+            print(f"[microbench] {nm:12s} {ops / (ms.value * 1e-3) / 1e12:8.3f} Tops/s  ({ms.value:.3f} ms)", file=sys.stderr)
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.log_n, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

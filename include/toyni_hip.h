@@ -1,0 +1,131 @@
+/*
+ * toyni_hip.h -- C ABI of libtoyni_hip.so: the MI355X (gfx950) backend for Toyni's BabyBear NTT and
+ * FRI fold.  This is the drop-in boundary: it is what `src/ntt.rs::cuda` (reference
+ * /root/reference/src/ntt.rs:95-110) binds, re-implemented from scratch in HIP.  Plain pointers and
+ * sizes only.  Every new entry point returns an int status (0 = success, otherwise a hipError_t value
+ * or one of the TOYNI_E_* codes below; toyni_error_string() names both).
+ *
+ * Element formats
+ *   host / "u64" : one uint64_t per element, canonical residue mod p = 2013265921
+ *                  (= #[repr(C)] struct BabyBear { value: u64 }, src/babybear.rs:10-14)
+ *   device "u32" : packed uint32_t canonical residues (the native device format; 8 B/element of HBM
+ *                  traffic per pass instead of 16).
+ *
+ * Threading: a context serialises its own calls with an internal mutex (the reference's shared d_data
+ * race, SURVEY.md F8, cannot happen).  Different contexts may be used concurrently.
+ */
+#ifndef TOYNI_HIP_H
+#define TOYNI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOYNI_OK 0
+#define TOYNI_E_INVALID_SIZE 10001   /* n not a power of two, or > 2^27 (src/ntt.rs:229-230) */
+#define TOYNI_E_NULL 10002           /* null context / pointer */
+#define TOYNI_E_ODD_LENGTH 10003     /* fri_fold: "Evaluations length must be even" (src/math/fri.rs:28) */
+#define TOYNI_E_NO_DEVICE 10004      /* no usable GPU ("CUDA not available", src/ntt.rs:225-227) */
+#define TOYNI_E_ZERO_INVERSE 10005   /* fri_fold: a point x_i = 0 ("Cannot invert zero", src/babybear.rs:112) */
+#define TOYNI_E_RANGE 10006          /* argument out of range (layer larger than the context's domain, ...) */
+
+typedef struct toyni_ntt_ctx toyni_ntt_ctx;
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. The reference's ABI, symbol for symbol (cuda/ntt_kernel.cu:211-318; extern block src/ntt.rs:95-110).
+ *    The reference's own src/ntt.rs links against these unchanged.  `count` is in u64 ELEMENTS.
+ * ---------------------------------------------------------------------------------------------- */
+void* ntt_ctx_create(uint32_t n);                       /* cuda/ntt_kernel.cu:213-234; NULL on error */
+void ntt_ctx_destroy(void* ctx);                        /* :236-242; null-safe */
+void ntt_run_inplace(void* ctx, uint64_t* h_data);      /* :249-268; host pointer, ctx->n elements, blocking */
+void intt_run_inplace(void* ctx, uint64_t* h_data);     /* :272-292 */
+int cuda_malloc(uint64_t** d_ptr, size_t count);        /* :298-300 */
+int cuda_free(uint64_t* d_ptr);                         /* :302-304 */
+int cuda_copy_to_device(uint64_t* d_dest, const uint64_t* h_src, size_t count);    /* :306-308 */
+int cuda_copy_from_device(uint64_t* h_dest, const uint64_t* d_src, size_t count);  /* :310-312 */
+const char* cuda_get_error_string(int error);           /* :314-316 */
+
+/* Replaces the raw `cudaGetDeviceCount` the reference takes from libcudart (src/ntt.rs:102,147). */
+int toyni_device_count(int* count);
+const char* toyni_error_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Status-returning context API (superset of section 1)
+ * ---------------------------------------------------------------------------------------------- */
+/* n: power of two, 1 <= n <= 2^27.  device: HIP device ordinal, or -1 for the current device.
+ * Builds both directions' twiddle tables (cuda/ntt_kernel.cu:160-185,213-234) and owns a stream. */
+int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out);
+int toyni_ntt_ctx_destroy(toyni_ntt_ctx* ctx);
+uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* ctx);
+int toyni_ntt_ctx_device(const toyni_ntt_ctx* ctx);
+int toyni_ntt_ctx_passes(const toyni_ntt_ctx* ctx);     /* HBM sweeps per transform (1..3) */
+/* Multi-pass transforms of a large batch are issued in chunks of about chunk_elems elements so that the
+ * intermediate buffer stays cache-resident; 0 = whole batch at once (also env TOYNI_CHUNK_ELEMS). */
+int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);
+
+/* Host-slice entry points -- what ntt_cuda / intt_cuda (src/ntt.rs:224-251) call.  h_data: batch * n
+ * u64 elements, overwritten in place, natural order in and out, canonical root w_n.  Blocking.
+ * H2D -> narrow -> fused passes -> widen -> D2H. */
+int toyni_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, int inverse);
+
+/* Device-resident, packed u32, in place (d_in == d_out) or out of place.  Enqueued on `stream`
+ * (a hipStream_t; NULL = the context's own stream) and NOT synchronised: this is the entry point the
+ * roofline numbers are measured on.  batch transforms are contiguous (stride n). */
+int toyni_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, int inverse, void* stream);
+
+/* Device-resident on the reference's u64 element layout (what a CudaBuffer holds, src/ntt.rs:153-215). */
+int toyni_ntt_device_u64(toyni_ntt_ctx* ctx, uint64_t* d_data, size_t batch, int inverse, void* stream);
+
+/* Coset transforms of BabyBearDomain (src/math/domain.rs:85-123,154-174) with the host's serial
+ * shift^i loop fused on the device: forward = scale by shift^i then NTT; inverse = INTT then scale by
+ * shift^-i.  shift is a canonical nonzero residue; shift == 1 is the plain transform. */
+int toyni_coset_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream);
+int toyni_coset_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, uint64_t shift, int inverse);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. FRI pairwise fold (net-new on the device; oracle src/math/fri.rs:27-48)
+ *    out[i] = (a + b)/2 + (a - b)/2 * beta / x_i,  a = evals[i], b = evals[i + m/2],  i < m/2
+ * ---------------------------------------------------------------------------------------------- */
+/* Structured points x_i = x0 * w_m^i (the prover's layers: x0 = shift^(2^k), src/fibonacci.rs:214,228-231).
+ * ctx: any context whose n >= m (its inverse-root table is used).  m even power of two >= 2.  Async on stream. */
+int toyni_fri_fold_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, void* stream);
+
+/* The prover's whole fold loop (src/fibonacci.rs:222-245) without the Merkle commits: nfolds layers of
+ * a size-n codeword on the coset shift * <w_n>; layer k (size n >> (k+1)) is written at
+ * d_layers + (n - (n >> k)) ... i.e. back to back: n/2, n/4, ...  betas: host array of nfolds challenges. */
+int toyni_fri_fold_layers_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, uint32_t* d_layers, const uint32_t* betas, unsigned nfolds, uint32_t shift, void* stream);
+
+/* Explicit points, the reference's signature fri_fold(evals, xs, beta): only xs[0 .. m/2) is read. */
+int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint32_t* d_out, size_t m, uint32_t beta, void* stream);
+/* Host-slice form of the same (u64 elements, blocking): out has len/2 elements. */
+int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, uint64_t beta);
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Plumbing
+ * ---------------------------------------------------------------------------------------------- */
+int toyni_malloc(void** d_ptr, size_t bytes);
+int toyni_free(void* d_ptr);
+int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream);
+int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream);
+int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);
+int toyni_set_device(int device);
+
+/* Per-pass kernel timing for bench.py's roofline object: launches pass p of `batch` transforms `reps` times
+ * between HIP events on `stream` (pass 0 reads d_data, later passes the context's work buffer; values stay
+ * canonical but d_data's contents are overwritten).  ms_per_pass[p] = average launch duration in ms for
+ * p < toyni_ntt_ctx_passes(ctx).  Blocking. */
+int toyni_ntt_profile_passes(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream);
+
+/* Instruction-throughput probe used by bench.py --microbench (not part of the data path):
+ * which = 0 mont_mul, 1 barrett64, 2 add/sub, 3 mul_lo, 4 mul_hi, 5 mad_u64_u32.  Returns elapsed ms. */
+int toyni_microbench(int which, int iters, int blocks, float* ms_out, uint32_t* sink_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOYNI_HIP_H */

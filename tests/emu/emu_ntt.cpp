@@ -1,0 +1,164 @@
+// CPU stepping of the gfx950 kernel bodies (toyni_amd/csrc/ntt_kernels.hpp) against the oracle.
+//
+// TEST INFRASTRUCTURE.  The shipped library has no CPU path; this harness exists so that the index
+// algebra of every pass shape (tile maps, LDS swizzles, twiddle tables, digit reversal, pass
+// sequencing) is proven on the CPU before a GPU minute is spent.  A workgroup is emulated by
+// running phase1 for every thread id, then phase2 for every thread id (the one barrier of a pass).
+//
+// Build: g++ -O2 -std=c++17 -I toyni_amd/csrc tests/emu/emu_ntt.cpp oracle/toyni_oracle.c  (see tests/test_emu.py)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ntt_plan.hpp"
+
+extern "C" {
+uint64_t orc_bb_mul(uint64_t, uint64_t);
+uint64_t orc_bb_add(uint64_t, uint64_t);
+uint64_t orc_bb_sub(uint64_t, uint64_t);
+uint64_t orc_bb_inverse(uint64_t);
+uint64_t orc_bb_pow(uint64_t, uint64_t);
+int orc_ntt_canonical(uint64_t*, size_t);
+int orc_intt_canonical(uint64_t*, size_t);
+void orc_fill_splitmix(uint64_t*, size_t, uint64_t);
+void orc_fill_pattern_7i3(uint64_t*, size_t);
+int orc_fri_fold(uint64_t*, const uint64_t*, size_t, const uint64_t*, uint64_t);
+int orc_domain_elements(uint64_t*, size_t, uint64_t);
+}
+
+using namespace toyni;
+
+static int failures = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch) {
+    const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
+    if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
+    bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+        using P = decltype(pass);
+        std::vector<uint32_t> lds(P::LDS_WORDS + 1, 0xDEADBEEFu);
+        for (uint64_t b = 0; b < nblocks; ++b) {
+            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, (uint32_t)b, tid, lds.data());
+            if constexpr (P::TWO_STEP) {
+                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, (uint32_t)b, tid, lds.data());
+            }
+        }
+    });
+    CHECK(ok, "no pass instantiation for log_n=%d", plan.log_n);
+}
+
+static void test_field() {
+    uint64_t s = 12345;
+    auto next = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)((s >> 20) % BB_P); };
+    std::vector<uint32_t> edge = {0u, 1u, 2u, BB_P - 1, BB_P - 2, BB_HALF, BB_R1, BB_R2, 0x7FFFFFFFu % BB_P};
+    for (int it = 0; it < 200000; ++it) {
+        uint32_t a = it < 81 ? edge[it / 9] : next();
+        uint32_t b = it < 81 ? edge[it % 9] : next();
+        uint32_t want = (uint32_t)orc_bb_mul(a, b);
+        CHECK(mont_mul(a, to_mont(b)) == want, "mont_mul %u %u", a, b);
+        CHECK(mont_mul(a, to_mont_host(b)) == want, "to_mont_host %u %u", a, b);
+        CHECK(bb_mul_barrett64(a, b) == want, "barrett %u %u", a, b);
+        CHECK(bb_mul_plain(a, b) == want, "mul_plain %u %u", a, b);
+        CHECK(bb_add(a, b) == (uint32_t)orc_bb_add(a, b), "add %u %u", a, b);
+        CHECK(bb_sub(a, b) == (uint32_t)orc_bb_sub(a, b), "sub %u %u", a, b);
+        CHECK(mont_mul(bb_sub_lazy(a, b), to_mont(b)) == (uint32_t)orc_bb_mul(orc_bb_sub(a, b), b), "sub_lazy %u %u", a, b);
+        CHECK(bb_halve(a) == (uint32_t)orc_bb_mul(a, BB_HALF), "halve %u", a);
+        // lazy product accepts any u32 on the left
+        uint32_t any = a * 2654435761u;
+        CHECK(bb_reduce_2p(mont_mul_lazy(any, to_mont(b))) == (uint32_t)orc_bb_mul(any % BB_P, b), "lazy any %u %u", any, b);
+        if (it < 2000 && a) CHECK(bb_inv_dev(a) == (uint32_t)orc_bb_inverse(a), "inv %u", a);
+    }
+    CHECK(from_mont(BB_R1) == 1u, "R1");
+    CHECK(narrow_u64((uint64_t)BB_P + 5) == 5u, "narrow");
+}
+
+static void test_ntt(int log_n, uint64_t batch, int pattern) {
+    NttPlan plan;
+    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    const size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> ref(n * batch);
+    if (pattern == 0) orc_fill_splitmix(ref.data(), n * batch, 0x70796E69ull + ((uint64_t)log_n << 32));
+    else for (uint64_t b = 0; b < batch; ++b) orc_fill_pattern_7i3(ref.data() + b * n, n);
+    std::vector<uint32_t> in(n * batch), work(n * batch, 0xABABABABu), out(n * batch, 0xCDCDCDCDu);
+    for (size_t i = 0; i < n * batch; ++i) in[i] = (uint32_t)ref[i];
+
+    // forward, out of place
+    emu_transform(plan, false, in.data(), work.data(), out.data(), batch);
+    std::vector<uint64_t> fwd = ref;
+    for (uint64_t b = 0; b < batch; ++b) orc_ntt_canonical(fwd.data() + b * n, n);
+    size_t bad = 0;
+    for (size_t i = 0; i < n * batch; ++i) if (out[i] != (uint32_t)fwd[i]) { if (!bad) std::printf("  first fwd mismatch log_n=%d i=%zu got=%u want=%u\n", log_n, i, out[i], (uint32_t)fwd[i]); ++bad; }
+    CHECK(bad == 0, "forward log_n=%d batch=%llu: %zu mismatches", log_n, (unsigned long long)batch, bad);
+
+    // inverse of `in` (as evaluations), in place
+    std::vector<uint32_t> buf = in;
+    emu_transform(plan, true, buf.data(), work.data(), buf.data(), batch);
+    std::vector<uint64_t> inv = ref;
+    for (uint64_t b = 0; b < batch; ++b) orc_intt_canonical(inv.data() + b * n, n);
+    bad = 0;
+    for (size_t i = 0; i < n * batch; ++i) if (buf[i] != (uint32_t)inv[i]) { if (!bad) std::printf("  first inv mismatch log_n=%d i=%zu got=%u want=%u\n", log_n, i, buf[i], (uint32_t)inv[i]); ++bad; }
+    CHECK(bad == 0, "inverse log_n=%d batch=%llu: %zu mismatches", log_n, (unsigned long long)batch, bad);
+
+    // roundtrip in place: intt(ntt(x)) == x  (src/ntt.rs:289-310)
+    emu_transform(plan, false, out.data(), work.data(), out.data(), batch);   // out = ntt(ntt(x)) -- just exercising in-place forward
+    buf = in;
+    emu_transform(plan, false, buf.data(), work.data(), buf.data(), batch);
+    emu_transform(plan, true, buf.data(), work.data(), buf.data(), batch);
+    CHECK(buf == in, "roundtrip log_n=%d", log_n);
+}
+
+static void test_fold(int log_N, int layer, uint32_t shift) {
+    NttPlan plan;
+    CHECK(build_plan(log_N, plan), "plan");
+    const size_t N = (size_t)1 << log_N, m = N >> layer, half = m / 2;
+    std::vector<uint64_t> evals(m), xs(N), want(half);
+    orc_fill_splitmix(evals.data(), m, 77 + layer);
+    orc_domain_elements(xs.data(), N, shift);
+    for (int k = 0; k < layer; ++k) for (size_t i = 0; i < N; ++i) xs[i] = orc_bb_mul(xs[i], xs[i]);  // src/fibonacci.rs:228-231
+    const uint64_t beta = 1234567 + layer;
+    orc_fri_fold(want.data(), evals.data(), m, xs.data(), beta);
+
+    std::vector<uint32_t> e32(m), out(half);
+    for (size_t i = 0; i < m; ++i) e32[i] = (uint32_t)evals[i];
+    FoldArgs f{};
+    f.evals = e32.data();
+    f.out = out.data();
+    f.inv_lo = plan.inv.data() + plan.dom_lo_off;
+    f.inv_hi = plan.inv.data() + plan.dom_hi_off;
+    f.lowbits = plan.dom_lowbits;
+    f.log_step = (uint32_t)layer;
+    const uint32_t x0 = (uint32_t)xs[0];
+    f.coef = to_mont_host(bb_mul_host(bb_mul_host((uint32_t)beta, BB_HALF), bb_inv_host(x0)));
+    f.half = half;
+    for (size_t i = 0; i < half; ++i) out[i] = fold_one(f, i, e32[i], e32[i + half]);
+    size_t bad = 0;
+    for (size_t i = 0; i < half; ++i) if (out[i] != (uint32_t)want[i]) ++bad;
+    CHECK(bad == 0, "fold log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
+}
+
+int main(int argc, char** argv) {
+    int max_log = argc > 1 ? std::atoi(argv[1]) : 16;
+    test_field();
+    std::printf("field ok=%d\n", failures == 0);
+    for (int log_n = 0; log_n <= max_log; ++log_n) {
+        test_ntt(log_n, 1, 0);
+        test_ntt(log_n, log_n <= 10 ? 70 : 3, 0);   // ragged row tiles for the single-pass kinds
+        if (log_n == 8) test_ntt(log_n, 1, 1);      // src/ntt.rs:263-287 input
+        std::printf("log_n=%d failures=%d\n", log_n, failures);
+        std::fflush(stdout);
+    }
+    for (int i = 2; i < argc; ++i) {                // extra sizes (2-pass 2^20, 3-pass 2^21..)
+        int log_n = std::atoi(argv[i]);
+        test_ntt(log_n, 1, 0);
+        std::printf("log_n=%d failures=%d\n", log_n, failures);
+        std::fflush(stdout);
+    }
+    for (int layer = 0; layer < 6; ++layer) test_fold(10, layer, 7);
+    test_fold(13, 0, 7);
+    test_fold(13, 12, 7);
+    test_fold(1, 0, 7);
+    test_fold(6, 2, 1);
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
+    return failures ? 1 : 0;
+}

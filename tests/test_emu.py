@@ -1,0 +1,14 @@
+"""Steps the gfx950 kernel bodies (toyni_amd/csrc/ntt_kernels.hpp) on the CPU against the oracle:
+every pass shape of the dispatch table, 1-, 2- and 3-pass plans, ragged batches, forward / inverse /
+round trip, and the structured FRI fold.  CPU only; the shipped library contains none of this."""
+import subprocess
+
+import __graft_entry__ as entry
+
+
+def test_kernel_bodies_match_oracle_on_cpu():
+    exe = entry.build_emu()
+    # sizes 2^0..2^14 (1- and 2-pass), plus 2^20 (the 1024 x 1024 headline split) and 2^21 (3-pass)
+    res = subprocess.run([exe, "14", "20", "21"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert "ALL OK" in res.stdout

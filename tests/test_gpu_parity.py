@@ -1,0 +1,441 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes over include/toyni_hip.h), against
+the oracle and the committed golden vectors -- bit-exact (integer path, no tolerance).
+
+The first three tests are the reference's own GPU tests (src/ntt.rs:253-311) restated; the rest widen
+them: every size 2^0..2^22, the golden vectors, edge vectors, ragged batches, the device-resident /
+u64 / coset entry points, the FRI fold in all its forms, and full-size (2^24, 2^27, 1024 x 2^20)
+runs checked through size-independent properties."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import toyni_amd
+    assert toyni_amd.gpu_available(), "GPU tests need a device"
+    return toyni_amd
+
+
+class DevBuf:
+    """Raw device allocation through the ABI's plumbing calls."""
+
+    def __init__(self, ta, nbytes):
+        self.lib = ta._lib.lib
+        p = ctypes.c_void_p()
+        ta._lib.check(self.lib.toyni_malloc(ctypes.byref(p), max(nbytes, 4)), "malloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert self.lib.toyni_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes) == 0
+
+    def download(self, dtype, count, offset=0):
+        out = np.empty(count, dtype=dtype)
+        assert self.lib.toyni_memcpy_d2h(out.ctypes.data, self.ptr + offset, out.nbytes) == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.toyni_free(self.ptr)
+            self.ptr = None
+
+
+def dev_transform(ta, x32, n, batch, inverse, inplace=True, shift=1, chunk=None):
+    ctx = ta.ntt.get_or_create_ctx(n)
+    if chunk is not None:
+        ctx.set_chunk(chunk)
+    a = DevBuf(ta, x32.nbytes)
+    b = a if inplace else DevBuf(ta, x32.nbytes)
+    try:
+        a.upload(x32)
+        ctx.run_device(a.ptr, b.ptr, batch, inverse, shift=shift)
+        ctx.synchronize()
+        return b.download(np.uint32, x32.size)
+    finally:
+        a.free()
+        if b is not a:
+            b.free()
+        if chunk is not None:
+            ctx.set_chunk(0)
+
+
+# ---------------------------------------------------------------- reference tests, src/ntt.rs:253-311
+def test_cuda_available(ta):
+    assert ta.cuda_available() is True
+
+
+def test_cuda_ntt_vs_cpu(ta):
+    n = 256
+    cpu_values = oracle.pattern_7i3(n)               # (i * 7 + 3), src/ntt.rs:272
+    gpu_values = cpu_values.copy()
+    omega = oracle.root_of_unity(8)
+    cpu_values = oracle.ntt(cpu_values, omega)       # cpu_ntt
+    ta.ntt_cuda(gpu_values)
+    for i, (c, g) in enumerate(zip(cpu_values, gpu_values)):
+        assert c == g, f"Mismatch at index {i}: CPU={c}, GPU={g}"
+
+
+def test_cuda_intt_roundtrip(ta):
+    n = 256
+    original = oracle.pattern_7i3(n)
+    values = original.copy()
+    ta.ntt_cuda(values)
+    ta.intt_cuda(values)
+    assert (values == original).all(), "Roundtrip failed"
+
+
+# ---------------------------------------------------------------- golden vectors
+def test_ntt_golden(ta, golden):
+    for c in golden["ntt"]:
+        v = np.array(c["input"], dtype=np.uint64)
+        ta.ntt_gpu(v)
+        assert v.tolist() == c["forward"], c["name"]
+        v = np.array(c["input"], dtype=np.uint64)
+        ta.intt_gpu(v)
+        assert v.tolist() == c["inverse"], c["name"]
+
+
+def test_kat_n8_polynomial_evaluation(ta):
+    # src/ntt.rs:338-357
+    v = np.array([1, 2, 3, 0, 0, 0, 0, 0], dtype=np.uint64)
+    ta.ntt_gpu(v)
+    assert v[0] == 6
+    x = oracle.root_of_unity(3)
+    assert v[1] == (1 + 2 * x + 3 * x * x) % P
+
+
+# ---------------------------------------------------------------- every size vs the oracle
+@pytest.mark.parametrize("log_n", list(range(0, 23)))
+def test_host_path_all_sizes(ta, log_n):
+    n = 1 << log_n
+    x = oracle.splitmix(n, 0x70796E69 + (log_n << 32))
+    v = x.copy()
+    ta.ntt_gpu(v)
+    assert (v == oracle.ntt(x)).all(), f"forward n=2^{log_n}"
+    v = x.copy()
+    ta.intt_gpu(v)
+    assert (v == oracle.intt(x)).all(), f"inverse n=2^{log_n}"
+
+
+@pytest.mark.parametrize("log_n", [20, 24])
+def test_headline_sizes_pattern_and_random(ta, log_n):
+    # BASELINE configs[1]: forward + inverse at n = 2^20 (and 2^24), bit-exact vs the CPU path, inputs I1 + I2
+    n = 1 << log_n
+    for x in (oracle.pattern_7i3(n), oracle.splitmix(n, 99)):
+        want = oracle.ntt(x)
+        got = dev_transform(ta, x.astype(np.uint32), n, 1, False)
+        assert (got == want).all()
+        back = dev_transform(ta, got, n, 1, True, inplace=False)
+        assert (back == x).all()
+
+
+def test_edge_vectors_n20(ta):
+    n = 1 << 20
+    ctx_root = oracle.root_of_unity(20)
+    zeros = np.zeros(n, dtype=np.uint32)
+    assert not dev_transform(ta, zeros, n, 1, False).any()
+    d0 = zeros.copy(); d0[0] = 1
+    assert (dev_transform(ta, d0, n, 1, False) == 1).all()                       # delta_0 -> all ones
+    d1 = zeros.copy(); d1[1] = 1
+    assert (dev_transform(ta, d1, n, 1, False) == oracle.roots_of_unity_domain(n)).all()  # delta_1 -> w^k
+    c = np.full(n, 123456789, dtype=np.uint32)
+    out = dev_transform(ta, c, n, 1, False)
+    assert out[0] == (123456789 * n) % P and not out[1:].any()                   # constant -> n c at 0
+    pm1 = np.full(n, P - 1, dtype=np.uint32)
+    out = dev_transform(ta, pm1, n, 1, False)
+    assert out[0] == ((P - 1) * n) % P and not out[1:].any()
+    assert ctx_root == 195061667
+
+
+# ---------------------------------------------------------------- batches, chunks, entry-point forms
+@pytest.mark.parametrize("log_n,batch", [(1, 1), (3, 70), (5, 257), (6, 33), (8, 19), (10, 9), (11, 5), (16, 5), (21, 2)])
+def test_batched_device_resident(ta, log_n, batch):
+    n = 1 << log_n
+    x = oracle.splitmix(n * batch, 7 + log_n).reshape(batch, n)
+    want = np.stack([oracle.ntt(r) for r in x])
+    got = dev_transform(ta, x.astype(np.uint32).reshape(-1), n, batch, False, inplace=False).reshape(batch, n)
+    assert (got == want).all()
+    back = dev_transform(ta, got.reshape(-1), n, batch, True).reshape(batch, n)
+    assert (back == x).all()
+
+
+def test_chunked_batch_equals_unchunked(ta):
+    n, batch = 1 << 12, 13
+    x = oracle.splitmix(n * batch, 5).astype(np.uint32)
+    a = dev_transform(ta, x, n, batch, False)
+    b = dev_transform(ta, x, n, batch, False, chunk=3 * n)      # 3 transforms per chunk, ragged tail
+    c = dev_transform(ta, x, n, batch, False, chunk=1)          # degenerate: 1 transform per chunk
+    assert (a == b).all() and (a == c).all()
+    assert (a.reshape(batch, n)[7] == oracle.ntt(x.reshape(batch, n)[7].astype(np.uint64))).all()
+
+
+def test_host_batch_and_noncanonical_input(ta):
+    n, batch = 1 << 9, 6
+    ctx = ta.ntt.get_or_create_ctx(n)
+    x = oracle.splitmix(n * batch, 17)
+    v = x.copy()
+    ctx.run_host(v, inverse=False, batch=batch)
+    assert (v.reshape(batch, n) == np.stack([oracle.ntt(r) for r in x.reshape(batch, n)])).all()
+    # a u64 that is not reduced behaves like BabyBear::new (src/babybear.rs:26-30)
+    y = x[:n].copy() + np.uint64(P)
+    ta.ntt_gpu(y)
+    assert (y == oracle.ntt(x[:n])).all()
+
+
+def test_u64_device_entry_and_cuda_buffer(ta):
+    n = 1 << 10
+    x = oracle.splitmix(n, 3)
+    buf = ta.CudaBuffer(n)                           # src/ntt.rs:153-215
+    buf.copy_from_host(x)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    ctx.run_device_u64(buf.as_ptr(), 1, False)
+    ctx.synchronize()
+    out = np.empty(n, dtype=np.uint64)
+    buf.copy_to_host(out)
+    assert (out == oracle.ntt(x)).all()
+    with pytest.raises(AssertionError, match="Size mismatch"):
+        buf.copy_from_host(x[:5])
+    buf.free()
+
+
+def test_legacy_void_abi(ta):
+    # the reference's own extern block: ntt_ctx_create / ntt_run_inplace / intt_run_inplace (src/ntt.rs:107-109)
+    lib = ta._lib.lib
+    n = 2048
+    ctx = lib.ntt_ctx_create(n)
+    assert ctx
+    x = oracle.splitmix(n, 8)
+    v = x.copy()
+    lib.ntt_run_inplace(ctx, v.ctypes.data)
+    assert (v == oracle.ntt(x)).all()
+    lib.intt_run_inplace(ctx, v.ctypes.data)
+    assert (v == x).all()
+    lib.ntt_ctx_destroy(ctx)
+    lib.ntt_ctx_destroy(None)
+
+
+def test_context_properties_and_errors(ta):
+    assert ta.NttContext(1 << 10).passes == 1
+    assert ta.ntt.get_or_create_ctx(1 << 20).passes == 2
+    assert ta.ntt.get_or_create_ctx(1 << 21).passes == 3
+    assert ta.ntt.get_or_create_ctx(1 << 20) is ta.ntt.get_or_create_ctx(1 << 20)   # per-n cache, src/ntt.rs:128-141
+    with pytest.raises(AssertionError, match="power of 2"):
+        ta.ntt_gpu(np.zeros(12, dtype=np.uint64))
+    with pytest.raises(TypeError):
+        ta.ntt_gpu([1, 2, 3, 4])
+
+
+def test_concurrent_calls_same_n(ta):
+    # parallel callers on the same n share one context; results must not interleave
+    import threading
+    n = 256
+    xs = [oracle.splitmix(n, 1000 + t) for t in range(8)]
+    outs = [None] * 8
+
+    def work(t):
+        for _ in range(20):
+            v = xs[t].copy()
+            ta.ntt_cuda(v)
+            outs[t] = v
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for t in range(8):
+        assert (outs[t] == oracle.ntt(xs[t])).all()
+
+
+# ---------------------------------------------------------------- coset transforms (BabyBearDomain)
+def test_domain_fft_ifft_roundtrip(ta):
+    # src/math/domain.rs:193-218
+    d = ta.BabyBearDomain(8).with_gpu(True)
+    coeffs = [(i * 3 + 1) % P for i in range(8)]
+    assert d.ifft(d.fft(coeffs)).tolist() == coeffs
+    coset = d.get_coset(7)
+    assert coset.ifft(coset.fft(coeffs)).tolist() == coeffs
+
+
+def test_coset_golden(ta, golden):
+    # src/math/domain.rs:220-242: coset FFT == Horner at every coset point
+    for c in golden["coset"]:
+        d = ta.BabyBearDomain(c["size"]).with_gpu(True).get_coset(c["shift"])
+        evals = d.fft(c["coeffs"])
+        assert evals.tolist() == c["evals"], c["name"]
+        back = d.ifft(evals).tolist()
+        assert back[: len(c["coeffs"])] == c["coeffs"] and not any(back[len(c["coeffs"]):])
+
+
+@pytest.mark.parametrize("log_n", [4, 10, 13, 21])
+def test_coset_vs_oracle(ta, log_n):
+    n = 1 << log_n
+    coeffs = oracle.splitmix(n // 2 + 3 if n > 8 else n, 31)
+    d = ta.BabyBearDomain(n).with_gpu(True).get_coset(7)
+    evals = d.fft(coeffs)
+    assert (evals == oracle.domain_fft(coeffs, n, 7)).all()
+    assert (d.ifft(evals) == oracle.domain_ifft(evals, 7)).all()
+    got = dev_transform(ta, evals.astype(np.uint32), n, 1, True, shift=7)
+    assert (got[: coeffs.size] == coeffs).all() and not got[coeffs.size:].any()
+
+
+def test_ext_transforms_are_four_base_transforms(ta):
+    # src/math/domain.rs:244-278
+    d = ta.BabyBearDomain(8).with_gpu(True)
+    coeffs = np.array([[(i * 3 + 1) % P, i + 2, i * 7, i + 5] for i in range(8)], dtype=np.uint64)
+    evals = d.fft_ext(coeffs)
+    for k in range(4):
+        assert (evals[:, k] == oracle.domain_fft(coeffs[:, k], 8)).all()
+    assert (d.ifft_ext(evals) == coeffs).all()
+
+
+# ---------------------------------------------------------------- FRI fold
+def test_fold_golden(ta, golden):
+    for c in golden["fold"]:
+        assert ta.fri_fold(c["evals"], c["xs"], c["beta"]).tolist() == c["folded"], c["name"]
+        assert ta.fri_fold(c["evals"], c["xs"][: c["n"] // 2], c["beta"]).tolist() == c["folded"]
+
+
+@pytest.mark.parametrize("m", [2, 6, 10, 4096, 1 << 16])
+def test_fold_xs_vs_oracle(ta, m):
+    # explicit points need not be a coset: random nonzero xs, any even length
+    evals = oracle.splitmix(m, 41)
+    xs = oracle.splitmix(m, 42) + np.uint64(1)
+    xs %= np.uint64(P)
+    xs[xs == 0] = 1
+    assert (ta.fri_fold(evals, xs, 987654321) == oracle.fri_fold(evals, xs, 987654321)).all()
+
+
+def test_fold_errors(ta):
+    with pytest.raises(AssertionError, match="even"):               # src/math/fri.rs:28
+        ta.fri_fold(np.zeros(5, dtype=np.uint64), np.ones(5, dtype=np.uint64), 1)
+    with pytest.raises(AssertionError, match="Cannot invert zero"):  # src/babybear.rs:112
+        ta.fri_fold(np.ones(4, dtype=np.uint64), np.array([1, 0], dtype=np.uint64), 1)
+    assert ta.fri_fold(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 1).size == 0
+
+
+@pytest.mark.parametrize("log_N,layer", [(1, 0), (3, 0), (10, 0), (10, 3), (10, 9), (16, 2), (21, 0), (21, 5)])
+def test_fold_structured_device_vs_oracle(ta, log_N, layer):
+    N = 1 << log_N
+    m = N >> layer
+    ctx = ta.ntt.get_or_create_ctx(N)
+    evals = oracle.splitmix(m, 51 + layer)
+    x0 = oracle.bb_pow(7, 1 << layer)
+    xs = oracle.domain_elements(m, x0)              # x0 * w_m^i
+    beta = 555555555
+    want = oracle.fri_fold(evals, xs, beta)
+    a, o = DevBuf(ta, m * 4), DevBuf(ta, m * 2)
+    a.upload(evals.astype(np.uint32))
+    ta.fri_fold_device(ctx, a.ptr, o.ptr, m, beta, x0)
+    ctx.synchronize()
+    got = o.download(np.uint32, m // 2)
+    a.free(); o.free()
+    assert (got == want).all()
+
+
+def test_fold_layers_golden_and_constant_final_layer(ta, golden):
+    # src/fibonacci.rs:220-245 + src/verifier.rs:69-75
+    c = golden["fold_layers"]
+    N = c["n"]
+    ctx = ta.ntt.get_or_create_ctx(N)
+    a, o = DevBuf(ta, N * 4), DevBuf(ta, N * 4)
+    a.upload(np.array(c["evals"], dtype=np.uint32))
+    ta.fri_fold_layers_device(ctx, a.ptr, o.ptr, c["betas"], c["shift"])
+    ctx.synchronize()
+    off = 0
+    for k, layer in enumerate(c["layers"]):
+        got = o.download(np.uint32, len(layer), offset=off * 4)
+        assert got.tolist() == layer, f"layer {k}"
+        off += len(layer)
+    assert len(set(c["layers"][-1])) == 1
+    a.free(); o.free()
+
+
+def test_prover_shape_fold_2_21(ta):
+    # BASELINE configs[2] shape: lde 2^21, degree bound 2^17 -> 17 folds 2^21 -> 2^4, final layer constant.
+    # Codeword = coset LDE (GPU coset FFT) of a random polynomial of degree < 2^17.
+    N, bound, shift = 1 << 21, 1 << 17, 7
+    coeffs = oracle.splitmix(bound, 61)
+    d = ta.BabyBearDomain(N).with_gpu(True).get_coset(shift)
+    evals = d.fft(coeffs)
+    betas = (oracle.splitmix(17, 62) % np.uint64(P)).astype(np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(N)
+    a, o = DevBuf(ta, N * 4), DevBuf(ta, N * 4)
+    a.upload(evals.astype(np.uint32))
+    ta.fri_fold_layers_device(ctx, a.ptr, o.ptr, betas, shift)
+    ctx.synchronize()
+    layers = oracle.fri_fold_layers(evals, shift, betas.astype(np.uint64))
+    off = 0
+    for k, want in enumerate(layers):
+        got = o.download(np.uint32, want.size, offset=off * 4)
+        assert (got == want).all(), f"layer {k}"
+        off += want.size
+    final = layers[-1]
+    assert final.size == 16 and len(set(final.tolist())) == 1    # src/verifier.rs:69-75
+    a.free(); o.free()
+
+
+# ---------------------------------------------------------------- full sizes through properties
+def _spot_check_dft(x32, out32, n, ks):
+    """out[k] == sum_j x[j] w^(jk) for a few k, by direct evaluation in numpy (uint64 products < 2^62)."""
+    w = oracle.roots_of_unity_domain(n)
+    x = x32.astype(np.uint64)
+    idx = np.arange(n, dtype=np.uint64)
+    for k in ks:
+        tw = w[(idx * np.uint64(k)) & np.uint64(n - 1)]
+        s = int(((x * tw) % np.uint64(P)).sum(dtype=np.uint64)) % P
+        assert int(out32[k]) == s, f"k={k}"
+
+
+def test_full_size_2_24_properties(ta):
+    n = 1 << 24
+    x = oracle.splitmix(n, 71).astype(np.uint32)
+    y = oracle.splitmix(n, 72).astype(np.uint32)
+    fx = dev_transform(ta, x, n, 1, False)
+    fy = dev_transform(ta, y, n, 1, False)
+    assert (dev_transform(ta, fx, n, 1, True) == x).all()                                   # round trip
+    s = ((x.astype(np.uint64) + y) % np.uint64(P)).astype(np.uint32)
+    fs = dev_transform(ta, s, n, 1, False)
+    assert (fs == ((fx.astype(np.uint64) + fy) % np.uint64(P)).astype(np.uint32)).all()    # linearity
+    _spot_check_dft(x, fx, n, [0, 1, 4097, n // 2, n - 1])
+
+
+def test_full_size_2_27_roundtrip(ta):
+    # the field's largest transform (2^28 does not exist)
+    n = 1 << 27
+    x = oracle.splitmix(n, 81).astype(np.uint32)
+    fx = dev_transform(ta, x, n, 1, False)
+    assert int(fx[0]) == int(x.sum(dtype=np.uint64)) % P                     # X[0] = sum x
+    d1 = np.zeros(n, dtype=np.uint32); d1[1] = 1
+    assert (dev_transform(ta, d1, n, 1, False) == oracle.roots_of_unity_domain(n)).all()    # every w^k, k < 2^27
+    assert (dev_transform(ta, fx, n, 1, True) == x).all()
+
+
+def test_batch_1024_x_2_20(ta):
+    # BASELINE configs[3] per-GPU shape: 1024 contiguous transforms of n = 2^20 (4 GiB packed)
+    n, batch, block = 1 << 20, 1024, 32
+    ctx = ta.ntt.get_or_create_ctx(n)
+    xb = oracle.splitmix(n * block, 91).astype(np.uint32)       # 32 distinct transforms, tiled 32x
+    buf = DevBuf(ta, n * batch * 4)
+    for r in range(batch // block):
+        buf.upload(xb, offset=r * xb.nbytes)
+    ctx.run_device(buf.ptr, buf.ptr, batch, False)
+    ctx.synchronize()
+    first = buf.download(np.uint32, n * block)
+    for b in (0, 17, 31):
+        assert (first[b * n:(b + 1) * n] == oracle.ntt(xb[b * n:(b + 1) * n].astype(np.uint64))).all()
+    for r in (1, 13, 31):                                        # every tile position gives the same answer
+        assert (buf.download(np.uint32, n * block, offset=r * xb.nbytes) == first).all()
+    ctx.run_device(buf.ptr, buf.ptr, batch, True)
+    ctx.synchronize()
+    for r in (0, 31):
+        assert (buf.download(np.uint32, n * block, offset=r * xb.nbytes) == xb).all()
+    buf.free()

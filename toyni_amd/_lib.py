@@ -1,0 +1,88 @@
+"""ctypes binding of libtoyni_hip.so (include/toyni_hip.h).  No fallback: a missing library is an error."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtoyni_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP backend is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). toyni_amd has no CPU path."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_int = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_u64 = ctypes.c_uint64
+c_size = ctypes.c_size_t
+c_void_p = ctypes.c_void_p
+p_u64 = ctypes.POINTER(ctypes.c_uint64)
+p_u32 = ctypes.POINTER(ctypes.c_uint32)
+
+# name -> (restype, argtypes); mirrors include/toyni_hip.h line by line
+SIGNATURES = {
+    # section 1: the reference's ABI
+    "ntt_ctx_create": (c_void_p, [c_u32]),
+    "ntt_ctx_destroy": (None, [c_void_p]),
+    "ntt_run_inplace": (None, [c_void_p, c_void_p]),
+    "intt_run_inplace": (None, [c_void_p, c_void_p]),
+    "cuda_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
+    "cuda_free": (c_int, [c_void_p]),
+    "cuda_copy_to_device": (c_int, [c_void_p, c_void_p, c_size]),
+    "cuda_copy_from_device": (c_int, [c_void_p, c_void_p, c_size]),
+    "cuda_get_error_string": (ctypes.c_char_p, [c_int]),
+    "toyni_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "toyni_error_string": (ctypes.c_char_p, [c_int]),
+    # section 2
+    "toyni_ntt_ctx_create": (c_int, [c_u32, c_int, ctypes.POINTER(c_void_p)]),
+    "toyni_ntt_ctx_destroy": (c_int, [c_void_p]),
+    "toyni_ntt_ctx_n": (c_u32, [c_void_p]),
+    "toyni_ntt_ctx_device": (c_int, [c_void_p]),
+    "toyni_ntt_ctx_passes": (c_int, [c_void_p]),
+    "toyni_ntt_ctx_set_chunk": (c_int, [c_void_p, c_size]),
+    "toyni_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_int]),
+    "toyni_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_int, c_void_p]),
+    "toyni_ntt_device_u64": (c_int, [c_void_p, c_void_p, c_size, c_int, c_void_p]),
+    "toyni_coset_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_int, c_void_p]),
+    "toyni_coset_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_u64, c_int]),
+    # section 3
+    "toyni_fri_fold_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p]),
+    "toyni_fri_fold_layers_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
+    "toyni_fri_fold_xs_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_void_p]),
+    "toyni_fri_fold_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_u64]),
+    # section 4
+    "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
+    "toyni_free": (c_int, [c_void_p]),
+    "toyni_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size]),
+    "toyni_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size]),
+    "toyni_narrow_u64_to_u32": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "toyni_widen_u32_to_u64": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
+    "toyni_set_device": (c_int, [c_int]),
+    "toyni_ntt_profile_passes": (c_int, [c_void_p, c_void_p, c_size, c_int, c_int, ctypes.POINTER(ctypes.c_float), c_void_p]),
+    "toyni_microbench": (c_int, [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_u32)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def error_string(status: int) -> str:
+    return lib.toyni_error_string(status).decode()
+
+
+class ToyniError(RuntimeError):
+    """Raised where the reference returns Err(String) (src/ntt.rs:163-166 pattern)."""
+
+    def __init__(self, what: str, status: int):
+        super().__init__(f"{what}: {error_string(status)}")
+        self.status = status
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise ToyniError(what, status)

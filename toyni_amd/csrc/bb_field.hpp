@@ -1,0 +1,123 @@
+// BabyBear arithmetic for the gfx950 kernels: p = 2^31 - 2^27 + 1.
+//
+// Data elements are canonical residues in packed u32 (the reference's element is a u64 holding the
+// same residue: src/babybear.rs:10-14; the u64 <-> u32 edge is toyni_hip.hip's narrow/widen).
+// Twiddles are stored in Montgomery form (w * 2^32 mod p) so that one product
+//     mont_mul(x, wR) = x * w mod p
+// costs two 32x32->64 multiply-adds (v_mad_u64_u32) and one 32-bit multiply, with a canonical
+// result after one conditional subtract.  Every function returns the exact canonical residue the
+// reference's `u128 % p` multiply (src/babybear.rs:169-178) and Barrett multiply
+// (cuda/ntt_kernel.cu:49-67) return; bb_mul_barrett64 below is the literal 64-bit Barrett of the
+// north-star text and is kept as the cross-check variant (tests/emu compares all of them).
+//
+// The file is plain C++ so that tests/emu can compile the kernel bodies with g++ and step them on
+// the CPU (test infrastructure; the shipped library contains device code only).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TOYNI_HD __host__ __device__ __forceinline__
+#define TOYNI_DEV __device__ __forceinline__
+#else
+#define TOYNI_HD inline
+#define TOYNI_DEV inline
+#endif
+
+namespace toyni {
+
+constexpr uint32_t BB_P = 2013265921u;          // src/babybear.rs:8
+constexpr uint64_t BB_BARRETT_MU = 9162596893ull; // floor(2^64 / p), cuda/ntt_kernel.cu:32
+
+// ---- compile-time helpers ----
+constexpr uint32_t cx_mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % BB_P); }
+constexpr uint32_t cx_powmod(uint32_t a, uint64_t e) {
+    uint32_t r = 1;
+    while (e) { if (e & 1) r = cx_mulmod(r, a); a = cx_mulmod(a, a); e >>= 1; }
+    return r;
+}
+// -p^-1 mod 2^32 by Newton iteration
+constexpr uint32_t cx_neg_pinv() {
+    uint32_t inv = 1;
+    for (int i = 0; i < 6; ++i) inv *= 2u - BB_P * inv;
+    return 0u - inv;
+}
+constexpr uint32_t BB_NPINV = cx_neg_pinv();                         // -p^-1 mod 2^32
+constexpr uint32_t BB_R1 = (uint32_t)((1ull << 32) % BB_P);          // R mod p   (Montgomery one)
+constexpr uint32_t BB_R2 = cx_mulmod(BB_R1, BB_R1);                  // R^2 mod p
+constexpr uint32_t BB_HALF = (BB_P + 1) / 2;                         // 2^-1 = 1006632961
+constexpr uint32_t BB_GEN_2_27 = 440564289u;                         // src/babybear.rs:122
+static_assert((uint32_t)(BB_P * (0u - BB_NPINV)) == 1u, "pinv");
+static_assert(BB_HALF == 1006632961u, "2^-1");
+
+// ---- canonical add / sub: one min() replaces compare+select ----
+// a, b in [0,p).  src/babybear.rs:129-139
+TOYNI_HD uint32_t bb_add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;               // < 2p < 2^32
+    uint32_t t = s - BB_P;            // wraps high when s < p
+    return s < t ? s : t;
+}
+// src/babybear.rs:148-160
+TOYNI_HD uint32_t bb_sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;               // wraps high when a < b
+    uint32_t t = d + BB_P;
+    return d < t ? d : t;
+}
+// a - b + p in (0, 2p): congruent to a - b, valid as the left operand of mont_mul_lazy
+TOYNI_HD uint32_t bb_sub_lazy(uint32_t a, uint32_t b) { return a + (BB_P - b); }
+// fold [0,2p) -> [0,p)
+TOYNI_HD uint32_t bb_reduce_2p(uint32_t x) {
+    uint32_t t = x - BB_P;
+    return x < t ? x : t;
+}
+// x / 2 mod p for canonical x
+TOYNI_HD uint32_t bb_halve(uint32_t x) { return (x >> 1) + ((x & 1u) ? BB_HALF : 0u); }
+
+// ---- Montgomery product, R = 2^32 ----
+// a: any u32, bR: Montgomery form of b with bR < p.  Returns a*b mod p up to one extra p: [0, 2p).
+// Also valid for a < p and bR < 2p (sum stays below 2^64 and the quotient below 2p).
+TOYNI_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t bR) {
+    uint64_t prod = (uint64_t)a * bR;
+    uint32_t m = (uint32_t)prod * BB_NPINV;
+    uint64_t t = prod + (uint64_t)m * BB_P;   // low 32 bits are zero by construction
+    return (uint32_t)(t >> 32);
+}
+TOYNI_HD uint32_t mont_mul(uint32_t a, uint32_t bR) { return bb_reduce_2p(mont_mul_lazy(a, bR)); }
+TOYNI_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, BB_R2); }
+TOYNI_HD uint32_t from_mont(uint32_t aR) { return mont_mul(aR, 1u); }
+
+// ---- plain products (host-side table building, cross-checks) ----
+// The north-star's "64-bit Barrett": q = hi64(prod * MU), r = prod - q p, one conditional subtract
+// (cuda/ntt_kernel.cu:49-67).
+TOYNI_HD uint32_t bb_mul_barrett64(uint32_t a, uint32_t b) {
+    uint64_t prod = (uint64_t)a * b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t q = __umul64hi(prod, BB_BARRETT_MU);
+#else
+    uint64_t q = (uint64_t)(((unsigned __int128)prod * BB_BARRETT_MU) >> 64);
+#endif
+    uint64_t r = prod - q * BB_P;
+    return (uint32_t)(r >= BB_P ? r - BB_P : r);
+}
+inline uint32_t bb_mul_host(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % BB_P); }
+inline uint32_t bb_pow_host(uint32_t a, uint64_t e) {
+    uint32_t r = 1;
+    while (e) { if (e & 1) r = bb_mul_host(r, a); a = bb_mul_host(a, a); e >>= 1; }
+    return r;
+}
+inline uint32_t bb_inv_host(uint32_t a) { return bb_pow_host(a, BB_P - 2); }          // src/babybear.rs:111-114
+inline uint32_t bb_root_of_unity_host(uint32_t log_n) {                                 // src/babybear.rs:118-126
+    return bb_pow_host(BB_GEN_2_27, 1ull << (27 - log_n));
+}
+inline uint32_t to_mont_host(uint32_t a) { return (uint32_t)((((uint64_t)a) << 32) % BB_P); }
+
+TOYNI_HD uint32_t bitrev32(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0u;
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1u); x >>= 1; }
+    return r;
+#endif
+}
+
+}  // namespace toyni

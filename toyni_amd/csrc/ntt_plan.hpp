@@ -1,0 +1,198 @@
+// Host-side plan of a size-n transform: how log2(n) is split into passes, and the twiddle tables
+// each pass reads.  Replaces build_twiddles_device / ntt_ctx_create of the reference
+// (cuda/ntt_kernel.cu:160-185, 213-234): instead of two packed tables of n-1 u64 each (2 GiB at
+// n = 2^27) a context holds, per direction, one packed stage table per distinct pass size (< 1024
+// words) and one two-level table per pass boundary (<= 24 K words), all u32 in Montgomery form.
+// Plain C++ (shared with tests/emu).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "bb_field.hpp"
+#include "ntt_kernels.hpp"
+
+namespace toyni {
+
+constexpr int MAX_PASSES = 3;
+constexpr int MAX_LOG_N = 27;  // BabyBear two-adicity, src/babybear.rs:119-125
+
+struct PassPlan {
+    int kind;      // PassKind
+    int log_m;     // log2 of this pass' sub-transform size
+    int log_s;     // KIND_COL: log2(columns per prefix block) = log2(n / (M_1..M_p))
+    // offsets (in u32 words) into the direction's table blob
+    uint32_t stage_off;
+    uint32_t lo_off, hi_off, lowbits;
+};
+
+struct NttPlan {
+    int log_n = 0;
+    int npasses = 0;
+    PassPlan pass[MAX_PASSES];
+    // domain table for the FRI fold: two-level w_n^-x (x < n), unscaled
+    uint32_t dom_lo_off = 0, dom_hi_off = 0, dom_lowbits = 0;
+    uint32_t scale_inv_1pass = 0;       // Montgomery form of n^-1 (only used when npasses == 1)
+    std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
+};
+
+// step split of a pass: LE1 high bits in step 1, LE2 low bits in step 2
+inline void split_steps(int log_m, int& le1, int& le2) {
+    if (log_m <= 5) { le1 = log_m; le2 = 0; }
+    else { le1 = (log_m + 1) / 2; le2 = log_m / 2; }
+}
+
+inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES]) {
+    if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
+    if (log_n <= 20) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
+    npasses = 3;
+    logm[0] = (log_n + 2) / 3;
+    logm[1] = (log_n + 1) / 3;
+    logm[2] = log_n / 3;
+}
+
+// packed stage table of size-M transform with root w_M: entry [2^t - 1 + x] = w_{2^(t+1)}^x, x < 2^t
+inline void append_stage_table(std::vector<uint32_t>& blob, int log_m, uint32_t w_m) {
+    for (int t = 0; t < log_m; ++t) {
+        const uint32_t w_len = bb_pow_host(w_m, 1ull << (log_m - (t + 1)));
+        uint32_t cur = 1;
+        for (uint32_t x = 0; x < (1u << t); ++x) {
+            blob.push_back(to_mont_host(cur));
+            cur = bb_mul_host(cur, w_len);
+        }
+    }
+}
+
+// two-level table of w (order 2^log_l): lo[x] = w^x (x < 2^lowbits), hi[y] = factor * w^(y << lowbits)
+inline void append_two_level(std::vector<uint32_t>& blob, int log_l, uint32_t w, uint32_t factor,
+                             uint32_t& lo_off, uint32_t& hi_off, uint32_t& lowbits) {
+    lowbits = (uint32_t)((log_l + 1) / 2);
+    lo_off = (uint32_t)blob.size();
+    uint32_t cur = 1;
+    for (uint32_t x = 0; x < (1u << lowbits); ++x) {
+        blob.push_back(to_mont_host(cur));
+        cur = bb_mul_host(cur, w);
+    }
+    hi_off = (uint32_t)blob.size();
+    const uint32_t w_hi = cur;  // w^(2^lowbits)
+    cur = factor;
+    for (uint32_t y = 0; y < (1u << (log_l - lowbits)); ++y) {
+        blob.push_back(to_mont_host(cur));
+        cur = bb_mul_host(cur, w_hi);
+    }
+}
+
+inline bool build_plan(int log_n, NttPlan& plan) {
+    if (log_n < 0 || log_n > MAX_LOG_N) return false;  // cuda/ntt_kernel.cu:217-220
+    plan.log_n = log_n;
+    int logm[MAX_PASSES];
+    split_passes(log_n, plan.npasses, logm);
+    const uint32_t w_n = bb_root_of_unity_host((uint32_t)log_n);      // cuda/ntt_kernel.cu:222-223
+    const uint32_t w_n_inv = bb_pow_host(w_n, (1ull << log_n) - 1);   // omega^(n-1), src/ntt.rs:59
+    const uint32_t n_inv = bb_inv_host((uint32_t)((1ull << log_n) % BB_P));  // src/ntt.rs:62
+    plan.scale_inv_1pass = to_mont_host(n_inv);
+
+    for (int dir = 0; dir < 2; ++dir) {
+        std::vector<uint32_t>& blob = dir ? plan.inv : plan.fwd;
+        blob.clear();
+        const uint32_t w = dir ? w_n_inv : w_n;
+        int consumed = 0;
+        for (int p = 0; p < plan.npasses; ++p) {
+            PassPlan& pp = plan.pass[p];
+            pp.log_m = logm[p];
+            const bool last = p == plan.npasses - 1;
+            pp.kind = plan.npasses == 1 ? KIND_ROW_N : (last ? KIND_ROW_T : KIND_COL);
+            const int log_l = log_n - consumed;       // L_p
+            pp.log_s = log_l - pp.log_m;
+            // root of the sub-transform: w_n^(n / M)
+            const uint32_t w_m = bb_pow_host(w, 1ull << (log_n - pp.log_m));
+            const uint32_t stage_off = (uint32_t)blob.size();
+            append_stage_table(blob, pp.log_m, w_m);
+            uint32_t lo_off = 0, hi_off = 0, lowbits = 0;
+            if (pp.kind == KIND_COL) {
+                const uint32_t w_l = bb_pow_host(w, 1ull << (log_n - log_l));
+                // n^-1 of the inverse transform rides on the first boundary's hi table
+                const uint32_t factor = (dir == 1 && p == 0) ? n_inv : 1u;
+                append_two_level(blob, log_l, w_l, factor, lo_off, hi_off, lowbits);
+            }
+            if (dir == 0) { pp.stage_off = stage_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
+            consumed += pp.log_m;
+        }
+        if (dir == 1) {
+            // unscaled inverse-root domain table for the FRI fold (x_i^-1 = x0^-1 * w_n^-i)
+            append_two_level(blob, log_n, w_n_inv, 1u, plan.dom_lo_off, plan.dom_hi_off, plan.dom_lowbits);
+        }
+    }
+    return true;
+}
+
+// (kind, log_m) -> Pass<...> instantiation.  This table is the single place that fixes the step split and
+// the tile width of every pass shape; f receives a value of the Pass type.
+template <class F>
+inline bool dispatch_pass(int kind, int log_m, F&& f) {
+#define TOYNI_PASS_CASE(K, A, B, LC_) \
+    if (kind == K && log_m == (A) + (B)) { f(Pass<K, A, B, LC_>{}); return true; }
+    // strided column passes (first / middle passes of a 2- or 3-pass transform)
+    TOYNI_PASS_CASE(KIND_COL, 3, 3, 5)
+    TOYNI_PASS_CASE(KIND_COL, 4, 3, 5)
+    TOYNI_PASS_CASE(KIND_COL, 4, 4, 5)
+    TOYNI_PASS_CASE(KIND_COL, 5, 4, 5)
+    TOYNI_PASS_CASE(KIND_COL, 5, 5, 4)
+    // last pass of a multi-pass transform: contiguous rows in, transposed (natural order) out
+    TOYNI_PASS_CASE(KIND_ROW_T, 5, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_T, 3, 3, 5)
+    TOYNI_PASS_CASE(KIND_ROW_T, 4, 3, 5)
+    TOYNI_PASS_CASE(KIND_ROW_T, 4, 4, 5)
+    TOYNI_PASS_CASE(KIND_ROW_T, 5, 4, 5)
+    TOYNI_PASS_CASE(KIND_ROW_T, 5, 5, 4)
+    // single-pass transforms (n <= 1024): one row per batch entry
+    TOYNI_PASS_CASE(KIND_ROW_N, 1, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_N, 2, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_N, 3, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_N, 4, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_N, 5, 0, 6)
+    TOYNI_PASS_CASE(KIND_ROW_N, 3, 3, 5)
+    TOYNI_PASS_CASE(KIND_ROW_N, 4, 3, 5)
+    TOYNI_PASS_CASE(KIND_ROW_N, 4, 4, 4)
+    TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 4)
+    TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
+#undef TOYNI_PASS_CASE
+    return false;
+}
+
+// Walks the passes of `batch` transforms src -> dst (src == dst allowed; `work` holds batch * n words and is
+// needed when npasses > 1).  `tables` points at the direction's blob wherever the executor can read it
+// (device memory for the HIP launcher, host memory for tests/emu).  launch(PassType{}, args, nblocks).
+// n = 1 launches nothing: the caller copies src to dst if they differ.
+template <class Launch>
+inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
+                          uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch) {
+    if (plan.log_n == 0 || batch == 0) return true;  // n = 1: identity
+    const uint64_t total_log = (uint64_t)plan.log_n;
+    for (int p = 0; p < plan.npasses; ++p) {
+        const PassPlan& pp = plan.pass[p];
+        PassArgs a{};
+        a.in = p == 0 ? src : work;
+        a.out = p == plan.npasses - 1 ? dst : work;
+        a.stage_tw = tables + pp.stage_off;
+        a.tw_lo = tables + pp.lo_off;
+        a.tw_hi = tables + pp.hi_off;
+        a.tw_lowbits = pp.lowbits;
+        a.log_S = (uint32_t)pp.log_s;
+        a.scale = (inverse && plan.npasses == 1) ? plan.scale_inv_1pass : 0u;
+        a.log_n = (uint32_t)plan.log_n;
+        a.log_M1 = (uint32_t)plan.pass[0].log_m;
+        a.log_mid = (uint32_t)(plan.log_n - plan.pass[0].log_m - pp.log_m);
+        a.rows_total = batch;
+        bool ok = dispatch_pass(pp.kind, pp.log_m, [&](auto pass) {
+            using P = decltype(pass);
+            uint64_t nblocks;
+            if (pp.kind == KIND_ROW_N) nblocks = (batch + P::C - 1) / P::C;
+            else nblocks = (batch << (total_log - P::LM)) / P::C;  // tiles of C columns / rows, each M long
+            launch(pass, a, nblocks);
+        });
+        if (!ok) return false;
+    }
+    return true;
+}
+
+}  // namespace toyni

@@ -1,0 +1,625 @@
+// libtoyni_hip.so -- gfx950 kernels + C ABI (include/toyni_hip.h).
+// Replaces cuda/ntt_kernel.cu of the reference; written for CDNA4 only (wave64, 160 KiB LDS, no MFMA:
+// the path is integer modular arithmetic).  Kernel bodies live in ntt_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/toyni_hip.h"
+#include "ntt_plan.hpp"
+
+using namespace toyni;
+
+#define HIPCHK(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return (int)_e;          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(P::T) ntt_pass_kernel(const PassArgs a) {
+    __shared__ uint32_t lds[P::LDS_WORDS ? P::LDS_WORDS : 1];
+    P::phase1(a, blockIdx.x, threadIdx.x, lds);
+    if constexpr (P::TWO_STEP) {
+        __syncthreads();
+        P::phase2(a, blockIdx.x, threadIdx.x, lds);
+    }
+}
+
+__global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = narrow_u64(in[i]);
+}
+
+__global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = in[i];
+}
+
+// out[b*n + i] = in[b*n + i] * s^i, s^i from a two-level table of the coset shift (src/math/domain.rs:154-174)
+__global__ void __launch_bounds__(256) coset_scale_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t total,
+                                                           uint32_t log_n, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                                           uint32_t lowbits) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint32_t nmask = (1u << log_n) - 1u, lmask = (1u << lowbits) - 1u;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t i = (uint32_t)g & nmask;
+        const uint32_t s = mont_mul(hi[i >> lowbits], lo[i & lmask]);
+        out[g] = mont_mul(in[g], s);
+    }
+}
+
+// FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows
+__global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
+    const uint64_t half = f.half;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if ((half & 3) == 0) {
+        const uint4* ea = reinterpret_cast<const uint4*>(f.evals);
+        const uint4* eb = reinterpret_cast<const uint4*>(f.evals + half);
+        uint4* o = reinterpret_cast<uint4*>(f.out);
+        for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < half / 4; q += stride) {
+            const uint4 a = ea[q], b = eb[q];
+            uint4 r;
+            r.x = fold_one(f, 4 * q + 0, a.x, b.x);
+            r.y = fold_one(f, 4 * q + 1, a.y, b.y);
+            r.z = fold_one(f, 4 * q + 2, a.z, b.z);
+            r.w = fold_one(f, 4 * q + 3, a.w, b.w);
+            o[q] = r;
+        }
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
+            f.out[i] = fold_one(f, i, f.evals[i], f.evals[i + half]);
+    }
+}
+
+// FRI fold, explicit points: 4 inversions share one Fermat exponentiation (Montgomery's trick)
+__global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
+                                                           uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half_R) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t groups = (half + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
+        uint32_t x[4], pre[4];
+        uint32_t acc = 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = 4 * q + j;
+            x[j] = i < half ? xs[i] : 1u;
+            pre[j] = acc;                       // product of x[0..j)
+            acc = bb_mul_plain(acc, x[j]);
+        }
+        uint32_t inv = bb_inv_dev(acc);         // 0 -> 0, like pow(0, p-2)
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const uint64_t i = 4 * q + j;
+            const uint32_t xinv = bb_mul_plain(inv, pre[j]);
+            inv = bb_mul_plain(inv, x[j]);
+            if (i < half) {
+                const uint32_t a = evals[i], b = evals[i + half];
+                const uint32_t avg = bb_halve(bb_add(a, b));
+                const uint32_t cw = mont_mul(xinv, beta_half_R);  // beta/2 * x^-1 (plain)
+                out[i] = bb_add(avg, bb_mul_plain(bb_sub(a, b), cw));
+            }
+        }
+    }
+}
+
+// instruction-throughput probe (8 independent chains per lane)
+template <int WHICH>
+__global__ void __launch_bounds__(256) microbench_kernel(uint32_t seed, int iters, uint32_t* sink) {
+    uint32_t x[8];
+    uint64_t y[8];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = (seed + t * 8u + j) % BB_P; y[j] = x[j]; }
+    const uint32_t w = (seed * 2654435761u) % BB_P;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (WHICH == 0) x[j] = mont_mul(x[j], w);
+            else if (WHICH == 1) x[j] = bb_mul_barrett64(x[j], w);
+            else if (WHICH == 2) x[j] = bb_sub(bb_add(x[j], w), seed);
+            else if (WHICH == 3) x[j] = x[j] * w + 1u;
+            else if (WHICH == 4) x[j] = __umulhi(x[j], w) + seed;
+            else y[j] = (uint64_t)(uint32_t)y[j] * w + y[j];
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc ^= x[j] ^ (uint32_t)y[j] ^ (uint32_t)(y[j] >> 32);
+    if (acc == 0xFFFFFFFFu) sink[0] = acc;  // practically never; keeps the chains live
+    if (t == 0) sink[1] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct ShiftTable {
+    uint32_t* d = nullptr;  // [fwd lo | fwd hi | inv lo | inv hi]
+    uint32_t lo_off[2], hi_off[2], lowbits;
+};
+
+struct toyni_ntt_ctx {
+    NttPlan plan;
+    uint32_t n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_fwd = nullptr;
+    uint32_t* d_inv = nullptr;
+    uint32_t* d_work = nullptr;      // intermediate passes (reference: NttCtx::d_data, cuda/ntt_kernel.cu:205)
+    size_t work_words = 0;
+    uint32_t* d_data32 = nullptr;    // packed copy for the host / u64 entry points
+    size_t data32_words = 0;
+    uint64_t* d_stage64 = nullptr;   // H2D / D2H staging on the reference's u64 layout
+    size_t stage64_elems = 0;
+    size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
+    std::map<uint32_t, ShiftTable> shifts;
+    std::mutex mu;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+int grow(void** buf, size_t* have, size_t need, size_t elem_bytes) {
+    if (*have >= need) return 0;
+    if (*buf) { HIPCHK(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    HIPCHK(hipMalloc(buf, need * elem_bytes));
+    *have = need;
+    return 0;
+}
+
+int grid_for(size_t items, int block = 256) {
+    size_t g = (items + block - 1) / block;
+    const size_t cap = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// enqueue the passes of `batch` transforms; d_in == d_out allowed
+int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s) {
+    if (batch == 0) return 0;
+    const size_t n = c->n;
+    if (c->plan.log_n == 0) {
+        if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    size_t chunk = batch;
+    if (c->chunk_elems && c->plan.npasses > 1) {
+        chunk = c->chunk_elems / n;
+        if (chunk < 1) chunk = 1;
+        if (chunk > batch) chunk = batch;
+    }
+    if (c->plan.npasses > 1) {
+        int rc = grow((void**)&c->d_work, &c->work_words, chunk * n, sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+        hipError_t err = hipSuccess;
+        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n, c->d_work, d_out + b0 * n, nb,
+                                [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+                                    using P = decltype(pass);
+                                    if (err != hipSuccess) return;
+                                    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);
+                                    err = hipGetLastError();
+                                });
+        if (!ok) return TOYNI_E_INVALID_SIZE;
+        if (err != hipSuccess) return (int)err;
+    }
+    return 0;
+}
+
+int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out) {
+    auto it = c->shifts.find(shift);
+    if (it != c->shifts.end()) { *out = &it->second; return 0; }
+    ShiftTable st;
+    std::vector<uint32_t> blob;
+    const uint32_t sinv = bb_inv_host(shift);  // src/math/domain.rs:167
+    for (int dir = 0; dir < 2; ++dir) {
+        // generic two-level powers of (shift or shift^-1): index i < n
+        const uint32_t base = dir ? sinv : shift;
+        st.lowbits = (uint32_t)((c->plan.log_n + 1) / 2);
+        st.lo_off[dir] = (uint32_t)blob.size();
+        uint32_t cur = 1;
+        for (uint32_t x = 0; x < (1u << st.lowbits); ++x) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, base); }
+        st.hi_off[dir] = (uint32_t)blob.size();
+        const uint32_t step = cur;
+        cur = 1;
+        for (uint32_t y = 0; y < (1u << (c->plan.log_n - st.lowbits)); ++y) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, step); }
+    }
+    HIPCHK(hipMalloc((void**)&st.d, blob.size() * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(st.d, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    auto ins = c->shifts.emplace(shift, st);
+    *out = &ins.first->second;
+    return 0;
+}
+
+int enqueue_coset_scale(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, bool inverse, hipStream_t s) {
+    ShiftTable* st = nullptr;
+    int rc = get_shift_table(c, shift, &st);
+    if (rc) return rc;
+    const size_t total = batch * (size_t)c->n;
+    const int dir = inverse ? 1 : 0;
+    hipLaunchKernelGGL(coset_scale_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, d_out, total, (uint32_t)c->plan.log_n,
+                       st->d + st->lo_off[dir], st->d + st->hi_off[dir], st->lowbits);
+    return (int)hipGetLastError();
+}
+
+bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
+int ilog2(size_t v) { int l = 0; while (((size_t)1 << l) < v) ++l; return l; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* toyni_error_string(int status) {
+    switch (status) {
+        case TOYNI_OK: return "success";
+        case TOYNI_E_INVALID_SIZE: return "NTT size must be a power of two and at most 2^27";
+        case TOYNI_E_NULL: return "null context or pointer";
+        case TOYNI_E_ODD_LENGTH: return "Evaluations length must be even";
+        case TOYNI_E_NO_DEVICE: return "no HIP device available";
+        case TOYNI_E_ZERO_INVERSE: return "Cannot invert zero";
+        case TOYNI_E_RANGE: return "argument out of range";
+        default: return hipGetErrorString((hipError_t)status);
+    }
+}
+
+int toyni_device_count(int* count) {
+    if (!count) return TOYNI_E_NULL;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); }
+    return (int)e;
+}
+
+int toyni_set_device(int device) { return (int)hipSetDevice(device); }
+
+int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
+    if (!out) return TOYNI_E_NULL;
+    *out = nullptr;
+    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    if (device >= count) return TOYNI_E_RANGE;
+    DeviceGuard guard(device);
+    toyni_ntt_ctx* c = new toyni_ntt_ctx();
+    c->n = n;
+    c->device = device;
+    if (!build_plan(ilog2(n), c->plan)) { delete c; return TOYNI_E_INVALID_SIZE; }
+    if (const char* env = std::getenv("TOYNI_CHUNK_ELEMS")) c->chunk_elems = (size_t)std::strtoull(env, nullptr, 0);
+    auto fail = [&](hipError_t e) { toyni_ntt_ctx_destroy(c); return (int)e; };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&c->d_fwd, c->plan.fwd.size() * sizeof(uint32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&c->d_inv, c->plan.inv.size() * sizeof(uint32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(c->d_fwd, c->plan.fwd.data(), c->plan.fwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(c->d_inv, c->plan.inv.data(), c->plan.inv.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    *out = c;
+    return TOYNI_OK;
+}
+
+int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
+    if (!c) return TOYNI_OK;
+    {
+        DeviceGuard guard(c->device);
+        if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+        (void)hipFree(c->d_fwd);
+        (void)hipFree(c->d_inv);
+        (void)hipFree(c->d_work);
+        (void)hipFree(c->d_data32);
+        (void)hipFree(c->d_stage64);
+        for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
+    }
+    delete c;
+    return TOYNI_OK;
+}
+
+uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
+int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
+int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
+
+int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* c, size_t chunk_elems) {
+    if (!c) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->chunk_elems = chunk_elems;
+    return TOYNI_OK;
+}
+
+int toyni_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, int inverse, void* stream) {
+    if (!c || !d_in || !d_out) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    return enqueue_transform(c, d_in, d_out, batch, inverse != 0, stream ? (hipStream_t)stream : c->stream);
+}
+
+int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream) {
+    if (!c || !d_in || !d_out) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (shift == 1) return enqueue_transform(c, d_in, d_out, batch, inverse != 0, s);  // src/math/domain.rs:155,166
+    int rc;
+    if (!inverse) {  // scale by shift^i, then NTT (src/math/domain.rs:111,121)
+        if ((rc = enqueue_coset_scale(c, d_in, d_out, batch, shift, false, s))) return rc;
+        return enqueue_transform(c, d_out, d_out, batch, false, s);
+    }
+    // INTT, then scale by shift^-i (src/math/domain.rs:99-100)
+    if ((rc = enqueue_transform(c, d_in, d_out, batch, true, s))) return rc;
+    return enqueue_coset_scale(c, d_out, d_out, batch, shift, true, s);
+}
+
+int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int inverse, void* stream) {
+    if (!c || !d_data) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t total = batch * (size_t)c->n;
+    if (!total) return TOYNI_OK;
+    int rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t));
+    if (rc) return rc;
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_data, c->d_data32, total);
+    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_data32, d_data, total);
+    return (int)hipGetLastError();
+}
+
+static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint32_t shift, int inverse) {
+    if (!c || !h_data) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const size_t total = batch * (size_t)c->n;
+    if (!total) return TOYNI_OK;
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, total, sizeof(uint64_t)))) return rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));  // cuda/ntt_kernel.cu:254
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_stage64, c->d_data32, total);
+    if (shift != 1 && !inverse) { if ((rc = enqueue_coset_scale(c, c->d_data32, c->d_data32, batch, shift, false, s))) return rc; }
+    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s))) return rc;
+    if (shift != 1 && inverse) { if ((rc = enqueue_coset_scale(c, c->d_data32, c->d_data32, batch, shift, true, s))) return rc; }
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_data32, c->d_stage64, total);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_data, c->d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));  // cuda/ntt_kernel.cu:267
+    HIPCHK(hipStreamSynchronize(s));
+    return TOYNI_OK;
+}
+
+int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse) { return host_transform(c, h_data, batch, 1u, inverse); }
+
+int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint64_t shift, int inverse) {
+    if (shift >= BB_P) shift %= BB_P;
+    return host_transform(c, h_data, batch, (uint32_t)shift, inverse);
+}
+
+// ---- FRI fold ----
+static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s) {
+    if (m % 2) return TOYNI_E_ODD_LENGTH;
+    if (m == 0) return TOYNI_OK;
+    if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
+    if (x0 == 0 || x0 >= BB_P || beta >= BB_P) return x0 == 0 ? TOYNI_E_ZERO_INVERSE : TOYNI_E_RANGE;
+    FoldArgs f{};
+    f.evals = d_evals;
+    f.out = d_out;
+    f.inv_lo = c->d_inv + c->plan.dom_lo_off;
+    f.inv_hi = c->d_inv + c->plan.dom_hi_off;
+    f.lowbits = c->plan.dom_lowbits;
+    f.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
+    f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
+    f.half = m / 2;
+    const size_t work = (f.half & 3) ? f.half : f.half / 4;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(work)), dim3(256), 0, s, f);
+    return (int)hipGetLastError();
+}
+
+int toyni_fri_fold_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, void* stream) {
+    if (!c || !d_evals || !d_out) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    return enqueue_fold(c, d_evals, d_out, m, beta, x0, stream ? (hipStream_t)stream : c->stream);
+}
+
+int toyni_fri_fold_layers_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_layers, const uint32_t* betas, unsigned nfolds,
+                                 uint32_t shift, void* stream) {
+    if (!c || !d_evals || !d_layers || (!betas && nfolds)) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P) return TOYNI_E_ZERO_INVERSE;
+    if (nfolds > (unsigned)c->plan.log_n) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const uint32_t* cur = d_evals;
+    uint32_t* dst = d_layers;
+    size_t m = c->n;
+    uint32_t x0 = shift;  // layer k points: (shift w^i)^(2^k) -- xs squared after every fold, src/fibonacci.rs:228-231
+    for (unsigned k = 0; k < nfolds; ++k) {
+        int rc = enqueue_fold(c, cur, dst, m, betas[k], x0, s);
+        if (rc) return rc;
+        cur = dst;
+        dst += m / 2;
+        m /= 2;
+        x0 = bb_mul_host(x0, x0);
+    }
+    return TOYNI_OK;
+}
+
+int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint32_t* d_out, size_t m, uint32_t beta, void* stream) {
+    if (!d_evals || !d_xs || !d_out) return TOYNI_E_NULL;
+    if (m % 2) return TOYNI_E_ODD_LENGTH;
+    if (m == 0) return TOYNI_OK;
+    if (beta >= BB_P) return TOYNI_E_RANGE;
+    const uint64_t half = m / 2;
+    const uint32_t beta_half_R = to_mont_host(bb_mul_host(beta, BB_HALF));
+    hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
+    return (int)hipGetLastError();
+}
+
+int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, uint64_t beta) {
+    if (!h_out || !h_evals || !h_xs) return TOYNI_E_NULL;
+    if (len % 2) return TOYNI_E_ODD_LENGTH;  // src/math/fri.rs:28
+    if (len == 0) return TOYNI_OK;
+    const size_t half = len / 2;
+    std::vector<uint32_t> e32(len), x32(half);
+    for (size_t i = 0; i < len; ++i) e32[i] = (uint32_t)(h_evals[i] % BB_P);
+    for (size_t i = 0; i < half; ++i) {
+        x32[i] = (uint32_t)(h_xs[i] % BB_P);
+        if (x32[i] == 0) return TOYNI_E_ZERO_INVERSE;  // src/babybear.rs:112
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    uint32_t *d_e = nullptr, *d_x = nullptr, *d_o = nullptr;
+    int rc = TOYNI_OK;
+    auto cleanup = [&]() { (void)hipFree(d_e); (void)hipFree(d_x); (void)hipFree(d_o); };
+#define FOLD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
+    FOLD_TRY(hipMalloc((void**)&d_e, len * sizeof(uint32_t)));
+    FOLD_TRY(hipMalloc((void**)&d_x, half * sizeof(uint32_t)));
+    FOLD_TRY(hipMalloc((void**)&d_o, half * sizeof(uint32_t)));
+    FOLD_TRY(hipMemcpy(d_e, e32.data(), len * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FOLD_TRY(hipMemcpy(d_x, x32.data(), half * sizeof(uint32_t), hipMemcpyHostToDevice));
+    rc = toyni_fri_fold_xs_device(d_e, d_x, d_o, len, (uint32_t)(beta % BB_P), nullptr);
+    if (rc) { cleanup(); return rc; }
+    FOLD_TRY(hipMemcpy(x32.data(), d_o, half * sizeof(uint32_t), hipMemcpyDeviceToHost));
+#undef FOLD_TRY
+    cleanup();
+    for (size_t i = 0; i < half; ++i) h_out[i] = x32[i];
+    return TOYNI_OK;
+}
+
+// ---- plumbing ----
+int toyni_malloc(void** d_ptr, size_t bytes) { return d_ptr ? (int)hipMalloc(d_ptr, bytes) : TOYNI_E_NULL; }
+int toyni_free(void* d_ptr) { return (int)hipFree(d_ptr); }
+int toyni_memcpy_h2d(void* d, const void* h, size_t bytes) { return (int)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); }
+int toyni_memcpy_d2h(void* h, const void* d, size_t bytes) { return (int)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost); }
+
+int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream) {
+    if (!d_in || !d_out) return TOYNI_E_NULL;
+    if (!count) return TOYNI_OK;
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, count);
+    return (int)hipGetLastError();
+}
+
+int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream) {
+    if (!d_in || !d_out) return TOYNI_E_NULL;
+    if (!count) return TOYNI_OK;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, count);
+    return (int)hipGetLastError();
+}
+
+int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
+    hipStream_t s = stream ? (hipStream_t)stream : (c ? c->stream : nullptr);
+    return (int)hipStreamSynchronize(s);
+}
+
+int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream) {
+    if (!c || !d_data || !ms_per_pass) return TOYNI_E_NULL;
+    if (reps < 1 || batch < 1) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->plan.log_n == 0) return TOYNI_OK;
+    if (c->plan.npasses > 1) {
+        int rc = grow((void**)&c->d_work, &c->work_words, batch * (size_t)c->n, sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int pass_index = 0;
+    hipError_t err = hipSuccess;
+    bool ok = for_each_pass(c->plan, tables, inverse != 0, d_data, c->d_work, d_data, batch,
+                            [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+                                using P = decltype(pass);
+                                if (err != hipSuccess) return;
+                                hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);  // warm
+                                (void)hipEventRecord(e0, s);
+                                for (int r = 0; r < reps; ++r)
+                                    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);
+                                (void)hipEventRecord(e1, s);
+                                err = hipEventSynchronize(e1);
+                                float ms = 0.f;
+                                if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+                                ms_per_pass[pass_index++] = ms / (float)reps;
+                            });
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return TOYNI_E_INVALID_SIZE;
+    return (int)err;
+}
+
+int toyni_microbench(int which, int iters, int blocks, float* ms_out, uint32_t* sink_out) {
+    if (!ms_out) return TOYNI_E_NULL;
+    uint32_t* d_sink = nullptr;
+    HIPCHK(hipMalloc((void**)&d_sink, 2 * sizeof(uint32_t)));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto launch = [&](int it) {
+        switch (which) {
+            case 0: hipLaunchKernelGGL(microbench_kernel<0>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+            case 1: hipLaunchKernelGGL(microbench_kernel<1>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+            case 2: hipLaunchKernelGGL(microbench_kernel<2>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+            case 3: hipLaunchKernelGGL(microbench_kernel<3>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+            case 4: hipLaunchKernelGGL(microbench_kernel<4>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+            default: hipLaunchKernelGGL(microbench_kernel<5>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
+        }
+    };
+    launch(iters / 8 + 1);  // warm
+    HIPCHK(hipEventRecord(e0, 0));
+    launch(iters);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
+    if (sink_out) HIPCHK(hipMemcpy(sink_out, d_sink + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_sink);
+    return TOYNI_OK;
+}
+
+// ---- the reference's ABI, symbol for symbol (include/toyni_hip.h section 1) ----
+void* ntt_ctx_create(uint32_t n) {
+    toyni_ntt_ctx* c = nullptr;
+    return toyni_ntt_ctx_create(n, -1, &c) == TOYNI_OK ? (void*)c : nullptr;  // cuda/ntt_kernel.cu:217-220: nullptr on error
+}
+void ntt_ctx_destroy(void* ctx) { (void)toyni_ntt_ctx_destroy((toyni_ntt_ctx*)ctx); }
+void ntt_run_inplace(void* ctx, uint64_t* h_data) {
+    int rc = toyni_ntt_host((toyni_ntt_ctx*)ctx, h_data, 1, 0);
+    if (rc) std::fprintf(stderr, "toyni_hip: ntt_run_inplace failed: %s\n", toyni_error_string(rc));  // void ABI: cannot return it
+}
+void intt_run_inplace(void* ctx, uint64_t* h_data) {
+    int rc = toyni_ntt_host((toyni_ntt_ctx*)ctx, h_data, 1, 1);
+    if (rc) std::fprintf(stderr, "toyni_hip: intt_run_inplace failed: %s\n", toyni_error_string(rc));
+}
+int cuda_malloc(uint64_t** d_ptr, size_t count) { return d_ptr ? (int)hipMalloc((void**)d_ptr, count * sizeof(uint64_t)) : TOYNI_E_NULL; }
+int cuda_free(uint64_t* d_ptr) { return (int)hipFree(d_ptr); }
+int cuda_copy_to_device(uint64_t* d_dest, const uint64_t* h_src, size_t count) {
+    return (int)hipMemcpy(d_dest, h_src, count * sizeof(uint64_t), hipMemcpyHostToDevice);
+}
+int cuda_copy_from_device(uint64_t* h_dest, const uint64_t* d_src, size_t count) {
+    return (int)hipMemcpy(h_dest, d_src, count * sizeof(uint64_t), hipMemcpyDeviceToHost);
+}
+const char* cuda_get_error_string(int error) { return toyni_error_string(error); }
+
+}  // extern "C"

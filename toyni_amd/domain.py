@@ -1,0 +1,67 @@
+"""Mirror of the caller of the hot path, `BabyBearDomain` (src/math/domain.rs:10-175), restricted to what
+reaches the GPU: fft / ifft with `use_gpu` set.  The coset pre/post scaling that the reference does in a
+serial host loop (src/math/domain.rs:154-174) runs on the device here."""
+import numpy as np
+
+from . import ntt as _ntt
+
+P = 2013265921
+
+
+class BabyBearDomain:
+    def __init__(self, size: int):
+        assert size > 0 and size & (size - 1) == 0, "Domain size must be power of 2"  # src/math/domain.rs:21
+        self.size = size
+        self.log_size = size.bit_length() - 1
+        self.shift = 1
+        self.use_gpu = False
+
+    def get_coset(self, shift: int) -> "BabyBearDomain":  # src/math/domain.rs:34-42
+        d = BabyBearDomain(self.size)
+        d.shift = int(shift) % P
+        d.use_gpu = self.use_gpu
+        return d
+
+    def with_gpu(self, use_gpu: bool) -> "BabyBearDomain":  # src/math/domain.rs:45-48
+        self.use_gpu = use_gpu
+        return self
+
+    def _require_gpu(self):
+        if not self.use_gpu:
+            raise NotImplementedError("toyni_amd ships the GPU backend only; the CPU transform is the reference's src/ntt.rs")
+        if not _ntt.gpu_available():
+            raise _ntt.ToyniError("GPU not available", 10004)
+
+    def fft(self, coeffs) -> np.ndarray:
+        """src/math/domain.rs:107-123: zero-pad to size, scale by shift^i, NTT."""
+        self._require_gpu()
+        c = np.asarray(coeffs, dtype=np.uint64)
+        assert c.size <= self.size
+        values = np.zeros(self.size, dtype=np.uint64)
+        values[: c.size] = c
+        _ntt.get_or_create_ctx(self.size).run_host(values, inverse=False, shift=self.shift)
+        return values
+
+    def ifft(self, evals) -> np.ndarray:
+        """src/math/domain.rs:85-102: INTT, then scale by shift^-i."""
+        self._require_gpu()
+        values = np.array(evals, dtype=np.uint64, copy=True)
+        assert values.size == self.size, "Evaluation count must match domain size"  # src/math/domain.rs:86
+        _ntt.get_or_create_ctx(self.size).run_host(values, inverse=True, shift=self.shift)
+        return values
+
+    def fft_ext(self, coeffs4) -> np.ndarray:
+        """src/math/domain.rs:134-151: four base transforms, issued as ONE batch of 4."""
+        return self._transform_ext(coeffs4, inverse=False)
+
+    def ifft_ext(self, evals4) -> np.ndarray:
+        return self._transform_ext(evals4, inverse=True)
+
+    def _transform_ext(self, vals4, inverse: bool) -> np.ndarray:
+        self._require_gpu()
+        v = np.asarray(vals4, dtype=np.uint64).reshape(-1, 4)
+        assert v.shape[0] <= self.size if not inverse else v.shape[0] == self.size
+        coords = np.zeros((4, self.size), dtype=np.uint64)  # de-interleave: src/math/domain.rs:141-147
+        coords[:, : v.shape[0]] = v.T
+        _ntt.get_or_create_ctx(self.size).run_host(coords.reshape(-1), inverse=inverse, batch=4, shift=self.shift)
+        return np.ascontiguousarray(coords.T)

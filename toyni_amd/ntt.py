@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's GPU wrapper `src/ntt.rs::cuda` (src/ntt.rs:85-315).
+
+Same names, argument meaning and error behaviour:
+  cuda_available()/gpu_available()    src/ntt.rs:144-150
+  ntt_cuda(values)/ntt_gpu(values)    src/ntt.rs:224-236   in place, canonical root, no omega argument
+  intt_cuda(values)/intt_gpu(values)  src/ntt.rs:239-251
+  CudaBuffer/GpuBuffer                src/ntt.rs:153-215   sizes in u64 ELEMENTS
+  get_or_create_ctx(n)                src/ntt.rs:128-141   process-lifetime per-n cache, never freed
+`values` is a C-contiguous numpy uint64 array: the same memory layout as `&mut [BabyBear]`
+(src/ntt.rs:112-116).  Errors that the reference returns as Err(String) raise ToyniError; its
+assert!s raise AssertionError with the same message.
+"""
+import ctypes
+import threading
+
+import numpy as np
+
+from ._lib import ToyniError, c_int, c_void_p, check, lib
+
+_ctx_cache = {}
+_ctx_lock = threading.Lock()
+
+
+def gpu_available() -> bool:
+    """src/ntt.rs:144-150: device-count call succeeded and count > 0."""
+    count = c_int(0)
+    err = lib.toyni_device_count(ctypes.byref(count))
+    return err == 0 and count.value > 0
+
+
+def get_or_create_ctx(n: int):
+    """src/ntt.rs:128-141."""
+    with _ctx_lock:
+        ctx = _ctx_cache.get(n)
+        if ctx is None:
+            ctx = NttContext(n)
+            _ctx_cache[n] = ctx
+        return ctx
+
+
+def _as_u64(values) -> np.ndarray:
+    if not (isinstance(values, np.ndarray) and values.dtype == np.uint64 and values.flags["C_CONTIGUOUS"] and values.flags["WRITEABLE"]):
+        raise TypeError("values must be a writable C-contiguous numpy uint64 array (the layout of &mut [BabyBear])")
+    return values
+
+
+def _checked_len(values) -> int:
+    n = values.size
+    assert n > 0 and n & (n - 1) == 0, "NTT size must be power of 2"  # src/ntt.rs:229
+    assert n.bit_length() - 1 <= 27, "BabyBear only supports NTT up to 2^27"  # src/ntt.rs:230
+    return n
+
+
+def ntt_gpu(values) -> None:
+    """src/ntt.rs:224-236."""
+    if not gpu_available():
+        raise ToyniError("GPU not available", 10004)
+    v = _as_u64(values)
+    n = _checked_len(v)
+    get_or_create_ctx(n).run_host(v, inverse=False)
+
+
+def intt_gpu(values) -> None:
+    """src/ntt.rs:239-251."""
+    if not gpu_available():
+        raise ToyniError("GPU not available", 10004)
+    v = _as_u64(values)
+    n = _checked_len(v)
+    get_or_create_ctx(n).run_host(v, inverse=True)
+
+
+class NttContext:
+    """Persistent per-n context: twiddles + reusable device buffers (NttCtx, cuda/ntt_kernel.cu:202-209)."""
+
+    def __init__(self, n: int, device: int = -1):
+        assert n > 0 and n & (n - 1) == 0, "NTT size must be power of 2"
+        assert n.bit_length() - 1 <= 27, "BabyBear only supports NTT up to 2^27"
+        h = c_void_p()
+        check(lib.toyni_ntt_ctx_create(n, device, ctypes.byref(h)), "NTT context creation failed")
+        self.handle = h
+        self.n = n
+
+    @property
+    def passes(self) -> int:
+        return lib.toyni_ntt_ctx_passes(self.handle)
+
+    def set_chunk(self, chunk_elems: int) -> None:
+        check(lib.toyni_ntt_ctx_set_chunk(self.handle, chunk_elems), "set_chunk failed")
+
+    def run_host(self, values: np.ndarray, inverse: bool, batch: int = 1, shift: int = 1) -> None:
+        """Host slice in place (batch * n u64 elements)."""
+        v = _as_u64(values)
+        assert v.size == batch * self.n, "Size mismatch"
+        if shift == 1:
+            check(lib.toyni_ntt_host(self.handle, v.ctypes.data, batch, int(inverse)), "GPU NTT failed")
+        else:
+            check(lib.toyni_coset_ntt_host(self.handle, v.ctypes.data, batch, shift, int(inverse)), "GPU coset NTT failed")
+
+    def run_device(self, d_in: int, d_out: int, batch: int, inverse: bool, stream: int = 0, shift: int = 1) -> None:
+        """Packed-u32 device pointers (ints), asynchronous on `stream` (0 = the context's own stream)."""
+        if shift == 1:
+            check(lib.toyni_ntt_device(self.handle, d_in, d_out, batch, int(inverse), stream or None), "GPU NTT failed")
+        else:
+            check(lib.toyni_coset_ntt_device(self.handle, d_in, d_out, batch, shift, int(inverse), stream or None), "GPU coset NTT failed")
+
+    def run_device_u64(self, d_data: int, batch: int, inverse: bool, stream: int = 0) -> None:
+        check(lib.toyni_ntt_device_u64(self.handle, d_data, batch, int(inverse), stream or None), "GPU NTT failed")
+
+    def profile_passes(self, d_data: int, batch: int, inverse: bool, reps: int = 20, stream: int = 0):
+        """Average launch duration (ms) of each pass kernel, HIP events on `stream` (bench.py's roofline)."""
+        out = (ctypes.c_float * 3)()
+        check(lib.toyni_ntt_profile_passes(self.handle, d_data, batch, int(inverse), reps, out, stream or None), "profile failed")
+        return [out[i] for i in range(self.passes)]
+
+    def synchronize(self, stream: int = 0) -> None:
+        check(lib.toyni_stream_synchronize(self.handle, stream or None), "stream synchronize failed")
+
+    def destroy(self) -> None:
+        if self.handle:
+            lib.toyni_ntt_ctx_destroy(self.handle)
+            self.handle = None
+
+
+class GpuBuffer:
+    """RAII device buffer of `size` u64 elements (CudaBuffer, src/ntt.rs:153-215)."""
+
+    def __init__(self, size: int):
+        p = c_void_p()
+        err = lib.cuda_malloc(ctypes.byref(p), size)
+        if err != 0:
+            raise ToyniError("GPU malloc failed", err)  # src/ntt.rs:163-166
+        self.ptr = p
+        self.size = size
+
+    def copy_from_host(self, data: np.ndarray) -> None:
+        assert data.size == self.size, "Size mismatch"  # src/ntt.rs:172
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        err = lib.cuda_copy_to_device(self.ptr, d.ctypes.data, self.size)
+        if err != 0:
+            raise ToyniError("GPU copy to device failed", err)
+
+    def copy_to_host(self, data: np.ndarray) -> None:
+        assert data.size == self.size, "Size mismatch"  # src/ntt.rs:187
+        v = _as_u64(data)
+        err = lib.cuda_copy_from_device(v.ctypes.data, self.ptr, self.size)
+        if err != 0:
+            raise ToyniError("GPU copy from device failed", err)
+
+    def as_ptr(self) -> int:
+        return self.ptr.value
+
+    def free(self) -> None:
+        if self.ptr:
+            lib.cuda_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):  # Drop, src/ntt.rs:206-212
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# the reference's names (Cargo feature `cuda`; src/ntt.rs:314-315) resolve to the same objects
+cuda_available = gpu_available
+ntt_cuda = ntt_gpu
+intt_cuda = intt_gpu
+CudaBuffer = GpuBuffer
