@@ -72,8 +72,9 @@ int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);
 int toyni_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, int inverse);
 
 /* Device-resident, packed u32, in place (d_in == d_out) or out of place.  Enqueued on `stream`
- * (a hipStream_t; NULL = the context's own stream) and NOT synchronised: this is the entry point the
- * roofline numbers are measured on.  batch transforms are contiguous (stride n). */
+ * (a hipStream_t; NULL = HIP's default stream, as everywhere in HIP) and NOT synchronised: this is the
+ * entry point the roofline numbers are measured on.  batch transforms are contiguous (stride n).
+ * One stream at a time per context (the intermediate buffer is shared). */
 int toyni_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, int inverse, void* stream);
 
 /* Device-resident on the reference's u64 element layout (what a CudaBuffer holds, src/ntt.rs:153-215). */
@@ -112,7 +113,7 @@ int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream);
 int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream);
-int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);
+int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); ctx unused */
 int toyni_set_device(int device);
 
 /* Per-pass kernel timing for bench.py's roofline object: launches pass p of `batch` transforms `reps` times

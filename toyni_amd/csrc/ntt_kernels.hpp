@@ -41,12 +41,21 @@ struct PassArgs {
     const uint32_t* tw_hi;     // KIND_COL: w_L^(y << tw_lowbits), y < L >> tw_lowbits
     uint32_t tw_lowbits;
     uint32_t log_S;            // KIND_COL: log2(columns per prefix block)
-    uint32_t scale;            // KIND_ROW_*: Montgomery form of a final factor (n^-1 for a 1-pass inverse); 0 = none
+    uint32_t scale;            // Montgomery form of an extra factor applied by this pass (n^-1 of the inverse transform); 0 = none
     uint32_t log_n;            // KIND_ROW_T: log2 n
     uint32_t log_M1;           // KIND_ROW_T: log2 M_1 (k_1 range the tile rows run over)
     uint32_t log_mid;          // KIND_ROW_T: log2(n / (M_1 * M)) -- number of middle digits (1 for P = 2)
     uint64_t rows_total;       // KIND_ROW_N: number of rows (= batch); tiles may be ragged
 };
+
+// base + 32-bit BYTE offset: keeps the address math in 32 bits so that global loads/stores take the
+// SGPR-base + VGPR-offset (+ immediate) form
+TOYNI_HD uint32_t ld32(const uint32_t* base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+TOYNI_HD void st32(uint32_t* base, uint32_t byte_off, uint32_t v) {
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 
 constexpr uint32_t cx_bitrev(uint32_t x, int bits) {
     uint32_t r = 0;
@@ -82,9 +91,12 @@ struct Pass {
         }
     }
 
+    // A tile is addressed as (uniform 64-bit base pointer) + (32-bit per-thread element offset): every offset inside
+    // a tile is < n <= 2^27, so the loads/stores use the SGPR-base + VGPR-offset form and no 64-bit VALU address math.
     struct Tile {
-        uint64_t in_base, out_base;
-        uint64_t in_cstride, in_rstride;   // element strides of (c, r) in the input
+        const uint32_t* in;
+        uint32_t* out;
+        uint32_t in_cshift_or_stride;       // KIND_ROW_T: log2 of the row stride; others unused
         uint32_t col0;                      // KIND_COL: first column index j' of the tile
         uint32_t valid_c;                   // KIND_ROW_N: rows of this tile that exist
     };
@@ -93,55 +105,80 @@ struct Pass {
         Tile t;
         t.col0 = 0;
         t.valid_c = C;
+        t.in_cshift_or_stride = 0;
         if (KIND == KIND_COL) {
             const uint32_t tiles_log = a.log_S - LC;
             const uint64_t prefix = (uint64_t)bid >> tiles_log;
             t.col0 = (bid & ((1u << tiles_log) - 1)) << LC;
-            t.in_base = (prefix << (a.log_S + LM)) + t.col0;
-            t.out_base = t.in_base;
-            t.in_cstride = 1;
-            t.in_rstride = (uint64_t)1 << a.log_S;
+            const uint64_t base = (prefix << (a.log_S + LM)) + t.col0;
+            t.in = a.in + base;
+            t.out = a.out + base;
         } else if (KIND == KIND_ROW_T) {
             const uint32_t mid = bid & ((1u << a.log_mid) - 1);
             const uint32_t k1_tiles_log = a.log_M1 - LC;
             const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << LC;
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
-            const uint64_t row_stride = (uint64_t)1 << (a.log_n - a.log_M1);
-            t.in_base = (b << a.log_n) + (uint64_t)k1_0 * row_stride + ((uint64_t)mid << LM);
-            t.in_cstride = row_stride;
-            t.in_rstride = 1;
-            t.out_base = (b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1);
+            t.in_cshift_or_stride = a.log_n - a.log_M1;
+            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.in_cshift_or_stride) + ((uint64_t)mid << LM));
+            t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
         } else {
             const uint64_t row0 = (uint64_t)bid << LC;
-            t.in_base = row0 << LM;
-            t.out_base = t.in_base;
-            t.in_cstride = M;
-            t.in_rstride = 1;
+            t.in = a.in + (row0 << LM);
+            t.out = a.out + (row0 << LM);
             const uint64_t left = a.rows_total - row0;
             t.valid_c = left < C ? (uint32_t)left : C;
         }
         return t;
     }
 
-    // the inter-pass twiddle w_L^(j' k) from the two-level table (both halves Montgomery form)
-    static TOYNI_HD uint32_t interpass_tw(const PassArgs& a, uint32_t jcol, uint32_t k) {
-        const uint32_t e = jcol * k;  // < L <= 2^27
+    // element offset of tile element (c, r) in the input
+    static TOYNI_HD uint32_t in_offset(const PassArgs& a, const Tile& t, uint32_t c, uint32_t r) {
+        if (KIND == KIND_COL) return (r << a.log_S) + c;
+        if (KIND == KIND_ROW_T) return (c << t.in_cshift_or_stride) + r;
+        return (c << LM) + r;
+    }
+    // element offset of finished element (c, natural sub-index k) in the output
+    static TOYNI_HD uint32_t out_offset(const PassArgs& a, uint32_t c, uint32_t k) {
+        if (KIND == KIND_COL) return (k << a.log_S) + c;
+        if (KIND == KIND_ROW_T) return c + (k << (a.log_n - LM));
+        return (c << LM) + k;
+    }
+
+    // w_L^e (Montgomery form, canonical) from the pass boundary's two-level table
+    static TOYNI_HD uint32_t boundary_tw(const PassArgs& a, uint32_t e) {
         const uint32_t lo = a.tw_lo[e & ((1u << a.tw_lowbits) - 1)];
         const uint32_t hi = a.tw_hi[e >> a.tw_lowbits];
         return mont_mul(hi, lo);
     }
 
-    // store finished element (c, natural sub-index k)
-    static TOYNI_HD void emit(const PassArgs& a, const Tile& t, uint32_t c, uint32_t k, uint32_t v) {
+    // Finish and store the NB = 2^LB elements a thread holds for one (c, khi): register i holds natural sub-index
+    // k = (bitrev(i) << LSH) | khi.  KIND_COL multiplies by the inter-pass twiddle w_L^(j' k) = A * G^bitrev(i) with
+    // A = w_L^(j' khi), G = w_L^(j' << LSH): two table lookups per thread and one running product, instead of a
+    // gather per element (the inverse's n^-1, a.scale on the first pass, is folded into A).
+    template <int LB, int LSH>
+    static TOYNI_HD void finish(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi, uint32_t (&x)[1 << LB]) {
+        constexpr uint32_t NB = 1u << LB;
+        // out_offset is linear in k: element b sits at off0 + b * step (bytes)
+        const uint32_t off0 = out_offset(a, c, khi) << 2;
+        const uint32_t step = (out_offset(a, 0u, 1u << LSH) - out_offset(a, 0u, 0u)) << 2;
         if (KIND == KIND_COL) {
-            v = mont_mul(v, interpass_tw(a, t.col0 + c, k));  // k = 0 too: the inverse's n^-1 rides on tw_hi
-            a.out[t.out_base + ((uint64_t)k << a.log_S) + c] = v;
-        } else if (KIND == KIND_ROW_T) {
-            if (a.scale) v = mont_mul(v, a.scale);
-            a.out[t.out_base + c + ((uint64_t)k << (a.log_n - LM))] = v;
+            const uint32_t jcol = t.col0 + c;
+            uint32_t tw = boundary_tw(a, jcol * khi);
+            if (a.scale) tw = mont_mul(tw, a.scale);
+            const uint32_t g = boundary_tw(a, jcol << LSH);
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) {
+                st32(t.out, off0 + b * step, mont_mul(x[cx_bitrev(b, LB)], tw));
+                if (b + 1 < NB) tw = mont_mul(tw, g);
+            }
         } else {
-            if (a.scale) v = mont_mul(v, a.scale);
-            a.out[t.out_base + (uint64_t)c * M + k] = v;
+            const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) {
+                uint32_t v = x[cx_bitrev(b, LB)];
+                if (scaled) v = mont_mul(v, a.scale);
+                st32(t.out, off0 + b * step, v);
+            }
         }
     }
 
@@ -162,7 +199,8 @@ struct Pass {
                 if (i & d) continue;
                 const uint32_t u = x[i], v = x[i + d];
                 x[i] = bb_add(u, v);
-                x[i + d] = mont_mul(bb_sub_lazy(u, v), w[i & (d - 1)]);
+                if (SHIFT == 0 && (i & (d - 1)) == 0) x[i + d] = bb_sub(u, v);  // twiddle w^0 = 1 (known at compile time)
+                else x[i + d] = mont_mul(bb_sub_lazy(u, v), w[i & (d - 1)]);
             }
         }
     }
@@ -172,13 +210,19 @@ struct Pass {
         uint32_t c, lo;
         if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
         else { lo = tid & (E2 - 1); c = tid >> LE2; }
-        const bool live = c < t.valid_c;
+        const bool live = KIND != KIND_ROW_N || c < t.valid_c;  // only single-pass row tiles can be ragged
 
         uint32_t x[E1];
-        const uint32_t* src = a.in + t.in_base + (uint64_t)c * t.in_cstride + (uint64_t)lo * t.in_rstride;
-        const uint64_t istep = t.in_rstride << LE2;
+        // in_offset is linear in r: register i sits at off0 + i * step (bytes)
+        const uint32_t off0 = in_offset(a, t, c, lo) << 2;
+        const uint32_t step = (in_offset(a, t, 0u, E2) - in_offset(a, t, 0u, 0u)) << 2;
+        if (live) {
 #pragma unroll
-        for (uint32_t i = 0; i < E1; ++i) x[i] = live ? src[i * istep] : 0u;
+            for (uint32_t i = 0; i < E1; ++i) x[i] = ld32(t.in, off0 + i * step);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < E1; ++i) x[i] = 0u;
+        }
 
         stages<LE1, LE2>(x, a.stage_tw, lo);
 
@@ -186,10 +230,7 @@ struct Pass {
 #pragma unroll
             for (uint32_t i = 0; i < E1; ++i) lds[lds_word(c, lo + (i << LE2))] = x[i];
         } else {
-            if (live) {
-#pragma unroll
-                for (uint32_t i = 0; i < E1; ++i) emit(a, t, c, cx_bitrev(i, LE1), x[i]);
-            }
+            if (live) finish<LE1, 0>(a, t, c, 0u, x);
         }
     }
 
@@ -202,17 +243,13 @@ struct Pass {
             if (KIND == KIND_ROW_N) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
             else { c = gamma & (C - 1); hi = gamma >> LC; }
 
-            uint32_t x[E2 ? E2 : 1];
+            uint32_t x[E2];
 #pragma unroll
             for (uint32_t i = 0; i < E2; ++i) x[i] = lds[lds_word(c, (hi << LE2) + i)];
 
-            stages<(LE2 ? LE2 : 1), 0>(x, a.stage_tw, 0u);
+            stages<LE2, 0>(x, a.stage_tw, 0u);
 
-            if (c < t.valid_c) {
-                const uint32_t khi = bitrev32(hi, LE1);
-#pragma unroll
-                for (uint32_t i = 0; i < E2; ++i) emit(a, t, c, (cx_bitrev(i, LE2) << LE1) | khi, x[i]);
-            }
+            if (KIND != KIND_ROW_N || c < t.valid_c) finish<LE2, LE1>(a, t, c, bitrev32(hi, LE1), x);
         }
     }
 };

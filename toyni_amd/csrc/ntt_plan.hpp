@@ -31,7 +31,7 @@ struct NttPlan {
     PassPlan pass[MAX_PASSES];
     // domain table for the FRI fold: two-level w_n^-x (x < n), unscaled
     uint32_t dom_lo_off = 0, dom_hi_off = 0, dom_lowbits = 0;
-    uint32_t scale_inv_1pass = 0;       // Montgomery form of n^-1 (only used when npasses == 1)
+    uint32_t scale_inv = 0;             // Montgomery form of n^-1, applied by the first pass of an inverse transform
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
 
@@ -89,7 +89,7 @@ inline bool build_plan(int log_n, NttPlan& plan) {
     const uint32_t w_n = bb_root_of_unity_host((uint32_t)log_n);      // cuda/ntt_kernel.cu:222-223
     const uint32_t w_n_inv = bb_pow_host(w_n, (1ull << log_n) - 1);   // omega^(n-1), src/ntt.rs:59
     const uint32_t n_inv = bb_inv_host((uint32_t)((1ull << log_n) % BB_P));  // src/ntt.rs:62
-    plan.scale_inv_1pass = to_mont_host(n_inv);
+    plan.scale_inv = to_mont_host(n_inv);
 
     for (int dir = 0; dir < 2; ++dir) {
         std::vector<uint32_t>& blob = dir ? plan.inv : plan.fwd;
@@ -110,9 +110,7 @@ inline bool build_plan(int log_n, NttPlan& plan) {
             uint32_t lo_off = 0, hi_off = 0, lowbits = 0;
             if (pp.kind == KIND_COL) {
                 const uint32_t w_l = bb_pow_host(w, 1ull << (log_n - log_l));
-                // n^-1 of the inverse transform rides on the first boundary's hi table
-                const uint32_t factor = (dir == 1 && p == 0) ? n_inv : 1u;
-                append_two_level(blob, log_l, w_l, factor, lo_off, hi_off, lowbits);
+                append_two_level(blob, log_l, w_l, 1u, lo_off, hi_off, lowbits);
             }
             if (dir == 0) { pp.stage_off = stage_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
             consumed += pp.log_m;
@@ -178,7 +176,7 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         a.tw_hi = tables + pp.hi_off;
         a.tw_lowbits = pp.lowbits;
         a.log_S = (uint32_t)pp.log_s;
-        a.scale = (inverse && plan.npasses == 1) ? plan.scale_inv_1pass : 0u;
+        a.scale = (inverse && p == 0) ? plan.scale_inv : 0u;  // src/ntt.rs:62-65, fused
         a.log_n = (uint32_t)plan.log_n;
         a.log_M1 = (uint32_t)plan.pass[0].log_m;
         a.log_mid = (uint32_t)(plan.log_n - plan.pass[0].log_m - pp.log_m);

@@ -349,7 +349,7 @@ int toyni_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, si
     if (!c || !d_in || !d_out) return TOYNI_E_NULL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    return enqueue_transform(c, d_in, d_out, batch, inverse != 0, stream ? (hipStream_t)stream : c->stream);
+    return enqueue_transform(c, d_in, d_out, batch, inverse != 0, (hipStream_t)stream);
 }
 
 int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream) {
@@ -357,7 +357,7 @@ int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_o
     if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     if (shift == 1) return enqueue_transform(c, d_in, d_out, batch, inverse != 0, s);  // src/math/domain.rs:155,166
     int rc;
     if (!inverse) {  // scale by shift^i, then NTT (src/math/domain.rs:111,121)
@@ -373,7 +373,7 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int i
     if (!c || !d_data) return TOYNI_E_NULL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     const size_t total = batch * (size_t)c->n;
     if (!total) return TOYNI_OK;
     int rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t));
@@ -438,7 +438,7 @@ int toyni_fri_fold_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d
     if (!c || !d_evals || !d_out) return TOYNI_E_NULL;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    return enqueue_fold(c, d_evals, d_out, m, beta, x0, stream ? (hipStream_t)stream : c->stream);
+    return enqueue_fold(c, d_evals, d_out, m, beta, x0, (hipStream_t)stream);
 }
 
 int toyni_fri_fold_layers_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_layers, const uint32_t* betas, unsigned nfolds,
@@ -448,7 +448,7 @@ int toyni_fri_fold_layers_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint
     if (nfolds > (unsigned)c->plan.log_n) return TOYNI_E_RANGE;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     const uint32_t* cur = d_evals;
     uint32_t* dst = d_layers;
     size_t m = c->n;
@@ -527,8 +527,8 @@ int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, 
 }
 
 int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
-    hipStream_t s = stream ? (hipStream_t)stream : (c ? c->stream : nullptr);
-    return (int)hipStreamSynchronize(s);
+    (void)c;
+    return (int)hipStreamSynchronize((hipStream_t)stream);
 }
 
 int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream) {
@@ -536,7 +536,7 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
     if (reps < 1 || batch < 1) return TOYNI_E_RANGE;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     if (c->plan.log_n == 0) return TOYNI_OK;
     if (c->plan.npasses > 1) {
         int rc = grow((void**)&c->d_work, &c->work_words, batch * (size_t)c->n, sizeof(uint32_t));

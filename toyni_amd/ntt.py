@@ -97,7 +97,7 @@ class NttContext:
             check(lib.toyni_coset_ntt_host(self.handle, v.ctypes.data, batch, shift, int(inverse)), "GPU coset NTT failed")
 
     def run_device(self, d_in: int, d_out: int, batch: int, inverse: bool, stream: int = 0, shift: int = 1) -> None:
-        """Packed-u32 device pointers (ints), asynchronous on `stream` (0 = the context's own stream)."""
+        """Packed-u32 device pointers (ints), asynchronous on `stream` (a hipStream_t handle; 0 = HIP default stream)."""
         if shift == 1:
             check(lib.toyni_ntt_device(self.handle, d_in, d_out, batch, int(inverse), stream or None), "GPU NTT failed")
         else:
