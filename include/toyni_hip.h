@@ -86,6 +86,12 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* ctx, uint64_t* d_data, size_t batch, int
 int toyni_coset_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream);
 int toyni_coset_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, uint64_t shift, int inverse);
 
+/* Multi-GPU 4-step transform of one size-n vector (n = n1 * n2 over G ranks, one all-to-all): the twiddle between
+ * the two local stages, d_data[r][k] *= w_n^(+-(row0 + r) * k) for r < rows, k < row_len (ctx of size n;
+ * (row0 + rows) * row_len <= n).  The local stages are toyni_ntt_device batches; the exchange is the caller's
+ * RCCL all-to-all (toyni_amd/dist.py). */
+int toyni_fourstep_twiddle_device(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t rows, size_t row_len, size_t row0, int inverse, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. FRI pairwise fold (net-new on the device; oracle src/math/fri.rs:27-48)
  *    out[i] = (a + b)/2 + (a - b)/2 * beta / x_i,  a = evals[i], b = evals[i + m/2],  i < m/2

@@ -439,3 +439,43 @@ def test_batch_1024_x_2_20(ta):
     for r in (0, 31):
         assert (buf.download(np.uint32, n * block, offset=r * xb.nbytes) == xb).all()
     buf.free()
+
+
+# ---------------------------------------------------------------- multi-GPU forms on one GPU (world = 1)
+@pytest.mark.parametrize("log_n", [10, 16, 22])
+def test_fourstep_world1_matches_oracle(ta, log_n):
+    # the 4-step driver of toyni_amd/dist.py with the HIP local stages; the all-to-all degenerates to a copy
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    x = oracle.splitmix(n, 300 + log_n)
+    ops = tdist.HipLocalOps(log_n, dev)
+    idx_in = tdist.fourstep_input_index(log_n, 1, 0).numpy()
+    cols = torch.from_numpy(x[idx_in].astype(np.int32)).to(dev)
+    out = tdist.fourstep_forward(cols, log_n, ops)
+    torch.cuda.synchronize()
+    idx = tdist.fourstep_output_index(log_n, 1, 0).numpy()
+    assert (out.cpu().numpy().astype(np.uint64) == oracle.ntt(x)[idx]).all()
+    back = tdist.fourstep_inverse(out, log_n, ops)
+    torch.cuda.synchronize()
+    assert torch.equal(back, cols)
+
+
+def test_fourstep_2_27_equals_single_device_transform(ta):
+    # BASELINE configs[4] at the field's limit n = 2^27, one rank: the 4-step path and the ordinary
+    # 3-pass transform must agree element for element
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    log_n = 27
+    n = 1 << log_n
+    x32 = oracle.splitmix(n, 2727).astype(np.uint32)
+    direct = dev_transform(ta, x32, n, 1, False)
+    ops = tdist.HipLocalOps(log_n, dev)
+    l1, l2 = tdist.fourstep_split(log_n, 1)
+    cols = torch.from_numpy(x32.view(np.int32).reshape(1 << l1, 1 << l2)).to(dev)
+    out = tdist.fourstep_forward(cols, log_n, ops)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)                     # [k1][k2] -> X[k1 + n1 k2]
+    assert (got.T.reshape(-1) == direct).all()

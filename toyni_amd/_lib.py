@@ -47,6 +47,7 @@ SIGNATURES = {
     "toyni_ntt_device_u64": (c_int, [c_void_p, c_void_p, c_size, c_int, c_void_p]),
     "toyni_coset_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_int, c_void_p]),
     "toyni_coset_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_u64, c_int]),
+    "toyni_fourstep_twiddle_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
     # section 3
     "toyni_fri_fold_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p]),
     "toyni_fri_fold_layers_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),

@@ -1,0 +1,114 @@
+// C++ host-side mirror of the reference's GPU wrapper module `src/ntt.rs::cuda` (src/ntt.rs:85-315),
+// over the C ABI of include/toyni_hip.h.  The reference is compiled code (Rust) whose toolchain is
+// absent here, so the host side above the ABI is written in C++ with the same names, argument
+// meaning and error behaviour: Result<(), String> becomes toyni::Result (empty = Ok), assert! becomes
+// an exception with the same message.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/toyni_hip.h"
+
+namespace toyni {
+
+// #[repr(C)] struct BabyBear { pub value: u64 }  (src/babybear.rs:10-14)
+struct BabyBear {
+    uint64_t value;
+};
+static_assert(sizeof(BabyBear) == sizeof(uint64_t) && alignof(BabyBear) == alignof(uint64_t), "layout (src/ntt.rs:115-116)");
+
+// Ok(()) / Err(String)
+struct Result {
+    std::string err;
+    bool is_ok() const { return err.empty(); }
+    void unwrap() const { if (!is_ok()) throw std::runtime_error(err); }
+};
+
+namespace ntt {
+
+inline bool gpu_available() {  // src/ntt.rs:144-150
+    int count = 0;
+    return toyni_device_count(&count) == 0 && count > 0;
+}
+
+// src/ntt.rs:128-141: process-lifetime per-n cache
+inline toyni_ntt_ctx* get_or_create_ctx(size_t n, std::string* err) {
+    static std::mutex mu;
+    static std::map<size_t, toyni_ntt_ctx*> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(n);
+    if (it != cache.end()) return it->second;
+    toyni_ntt_ctx* ctx = nullptr;
+    int st = toyni_ntt_ctx_create((uint32_t)n, -1, &ctx);
+    if (st != 0) { if (err) *err = std::string("GPU NTT context creation failed: ") + toyni_error_string(st); return nullptr; }
+    cache[n] = ctx;
+    return ctx;
+}
+
+inline Result transform(std::vector<BabyBear>& values, bool inverse) {
+    if (!gpu_available()) return {"GPU not available"};                                     // src/ntt.rs:225-227
+    const size_t n = values.size();
+    if (n == 0 || (n & (n - 1))) throw std::logic_error("NTT size must be power of 2");     // src/ntt.rs:229
+    if (n > (size_t(1) << 27)) throw std::logic_error("BabyBear only supports NTT up to 2^27");  // src/ntt.rs:230
+    std::string err;
+    toyni_ntt_ctx* ctx = get_or_create_ctx(n, &err);
+    if (!ctx) return {err};
+    int st = toyni_ntt_host(ctx, reinterpret_cast<uint64_t*>(values.data()), 1, inverse ? 1 : 0);
+    if (st != 0) return {std::string("GPU NTT failed: ") + toyni_error_string(st)};
+    return {};
+}
+
+inline Result ntt_gpu(std::vector<BabyBear>& values) { return transform(values, false); }   // src/ntt.rs:224-236
+inline Result intt_gpu(std::vector<BabyBear>& values) { return transform(values, true); }   // src/ntt.rs:239-251
+
+// src/ntt.rs:153-215; sizes in u64 elements
+class GpuBuffer {
+  public:
+    explicit GpuBuffer(size_t size) : size_(size) {
+        int st = cuda_malloc(&ptr_, size);
+        if (st != 0) throw std::runtime_error(std::string("GPU malloc failed: ") + cuda_get_error_string(st));
+    }
+    GpuBuffer(const GpuBuffer&) = delete;
+    GpuBuffer& operator=(const GpuBuffer&) = delete;
+    ~GpuBuffer() { cuda_free(ptr_); }
+    Result copy_from_host(const std::vector<uint64_t>& data) {
+        if (data.size() != size_) throw std::logic_error("Size mismatch");
+        int st = cuda_copy_to_device(ptr_, data.data(), size_);
+        return st ? Result{std::string("GPU copy to device failed: ") + cuda_get_error_string(st)} : Result{};
+    }
+    Result copy_to_host(std::vector<uint64_t>& data) const {
+        if (data.size() != size_) throw std::logic_error("Size mismatch");
+        int st = cuda_copy_from_device(data.data(), ptr_, size_);
+        return st ? Result{std::string("GPU copy from device failed: ") + cuda_get_error_string(st)} : Result{};
+    }
+    uint64_t* as_ptr() const { return ptr_; }
+
+  private:
+    uint64_t* ptr_ = nullptr;
+    size_t size_;
+};
+
+// the reference's names (feature `cuda`, src/ntt.rs:314-315)
+inline bool cuda_available() { return gpu_available(); }
+inline Result ntt_cuda(std::vector<BabyBear>& v) { return ntt_gpu(v); }
+inline Result intt_cuda(std::vector<BabyBear>& v) { return intt_gpu(v); }
+using CudaBuffer = GpuBuffer;
+
+}  // namespace ntt
+
+// src/math/fri.rs:27-48
+inline std::vector<BabyBear> fri_fold(const std::vector<BabyBear>& evals, const std::vector<BabyBear>& xs, BabyBear beta) {
+    if (evals.size() % 2) throw std::logic_error("Evaluations length must be even");
+    std::vector<BabyBear> out(evals.size() / 2);
+    int st = toyni_fri_fold_host(reinterpret_cast<uint64_t*>(out.data()), reinterpret_cast<const uint64_t*>(evals.data()), evals.size(),
+                                 reinterpret_cast<const uint64_t*>(xs.data()), beta.value);
+    if (st == TOYNI_E_ZERO_INVERSE) throw std::logic_error("Cannot invert zero");
+    if (st != 0) throw std::runtime_error(std::string("GPU FRI fold failed: ") + toyni_error_string(st));
+    return out;
+}
+
+}  // namespace toyni

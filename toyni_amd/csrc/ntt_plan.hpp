@@ -29,7 +29,7 @@ struct NttPlan {
     int log_n = 0;
     int npasses = 0;
     PassPlan pass[MAX_PASSES];
-    // domain table for the FRI fold: two-level w_n^-x (x < n), unscaled
+    // domain table: two-level w_n^x (fwd blob) / w_n^-x (inv blob), x < n
     uint32_t dom_lo_off = 0, dom_hi_off = 0, dom_lowbits = 0;
     uint32_t scale_inv = 0;             // Montgomery form of n^-1, applied by the first pass of an inverse transform
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
@@ -115,10 +115,9 @@ inline bool build_plan(int log_n, NttPlan& plan) {
             if (dir == 0) { pp.stage_off = stage_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
             consumed += pp.log_m;
         }
-        if (dir == 1) {
-            // unscaled inverse-root domain table for the FRI fold (x_i^-1 = x0^-1 * w_n^-i)
-            append_two_level(blob, log_n, w_n_inv, 1u, plan.dom_lo_off, plan.dom_hi_off, plan.dom_lowbits);
-        }
+        // domain table w_n^(+-x), x < n: the FRI fold reads the inverse one (x_i^-1 = x0^-1 * w_n^-i), the
+        // multi-GPU 4-step transform both (same offsets in both blobs)
+        append_two_level(blob, log_n, w, 1u, plan.dom_lo_off, plan.dom_hi_off, plan.dom_lowbits);
     }
     return true;
 }

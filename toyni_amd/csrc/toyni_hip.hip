@@ -57,6 +57,19 @@ __global__ void __launch_bounds__(256) coset_scale_kernel(const uint32_t* __rest
     }
 }
 
+// 4-step twiddle: data[r][k] *= w_n^(+-(row0 + r) k), r < rows, k < row_len (two-level domain table of the ctx)
+__global__ void __launch_bounds__(256) fourstep_twiddle_kernel(uint32_t* __restrict__ data, uint64_t total, uint32_t log_len, uint32_t row0,
+                                                                const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t lowbits) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lmask = (1u << lowbits) - 1u, kmask = (1u << log_len) - 1u;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint32_t k = (uint32_t)g & kmask;
+        const uint32_t e = (row0 + (uint32_t)(g >> log_len)) * k;  // < n <= 2^27
+        const uint32_t w = mont_mul(hi[e >> lowbits], lo[e & lmask]);
+        data[g] = mont_mul(data[g], w);
+    }
+}
+
 // FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows
 __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
     const uint64_t half = f.half;
@@ -412,6 +425,20 @@ int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse
 int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint64_t shift, int inverse) {
     if (shift >= BB_P) shift %= BB_P;
     return host_transform(c, h_data, batch, (uint32_t)shift, inverse);
+}
+
+// ---- multi-GPU 4-step helper: the twiddle between the two local transform stages ----
+int toyni_fourstep_twiddle_device(toyni_ntt_ctx* c, uint32_t* d_data, size_t rows, size_t row_len, size_t row0, int inverse, void* stream) {
+    if (!c || !d_data) return TOYNI_E_NULL;
+    if (!is_pow2(row_len) || (rows + row0) * row_len > (size_t)c->n || row_len > c->n) return TOYNI_E_RANGE;
+    if (!rows) return TOYNI_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const uint32_t* t = inverse ? c->d_inv : c->d_fwd;
+    const uint64_t total = (uint64_t)rows * row_len;
+    hipLaunchKernelGGL(fourstep_twiddle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_data, total, (uint32_t)ilog2(row_len),
+                       (uint32_t)row0, t + c->plan.dom_lo_off, t + c->plan.dom_hi_off, c->plan.dom_lowbits);
+    return (int)hipGetLastError();
 }
 
 // ---- FRI fold ----

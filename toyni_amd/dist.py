@@ -1,0 +1,140 @@
+"""Multi-GPU forms of the hot path; one process per GPU, torch.distributed for the plumbing.
+
+1. Batched same-size transforms (the prover's repeated workload, BASELINE configs[3]): independent units, so the
+   batch is sharded contiguously over ranks and NOTHING is exchanged -- `shard_batch` + the ordinary batched
+   entry point.  `max_over_ranks` is the only collective and it carries a timing scalar, not data.
+
+2. One transform too large / too slow for one GPU (configs[4], n up to the field's limit 2^27 -- SURVEY F1):
+   4-step decomposition n = n1 * n2 with exactly ONE all-to-all (RCCL over xGMI on GPUs):
+       X[k1 + n1 k2] = sum_j2 w_n2^(j2 k2) * [ w_n^(j2 k1) * sum_j1 x[j1 n2 + j2] w_n1^(j1 k1) ]
+   rank g starts with n2/G columns (j2 in its chunk), runs the n1-point column transforms and the twiddle
+   locally, the all-to-all turns column ownership into row ownership (k1 in its chunk), and the n2-point row
+   transforms finish.  Output layout: rank g holds X[k1 + n1 k2] for k1 in its chunk as a [n1/G, n2] array
+   (`fourstep_output_index` gives the natural index).  `fourstep_inverse` is the exact mirror.
+
+The reference has no counterpart (single device, no collectives: cuda/ntt_kernel.cu:246-248); values are pinned by
+the single-device transform / the oracle on the gathered result.
+
+The local work goes through a small `LocalOps` interface so that tests can run the SAME exchange logic over gloo
+on CPU tensors (tests/test_dist_cpu.py injects an oracle-backed LocalOps; this package ships only `HipLocalOps`).
+"""
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [start, start+count) of `total` independent transforms for `rank`; remainders go to the low ranks."""
+    base, rem = divmod(total, world)
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    """The bench contract's timing reduction (max over ranks).  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def fourstep_split(log_n: int, world: int) -> Tuple[int, int]:
+    """(log n1, log n2) with n1 >= n2 and both divisible by the world size."""
+    l1 = (log_n + 1) // 2
+    l2 = log_n - l1
+    assert world & (world - 1) == 0, "world size must be a power of two"
+    assert (1 << l2) >= world, "transform too small to split over this many ranks"
+    return l1, l2
+
+
+def fourstep_output_index(log_n: int, world: int, rank: int) -> torch.Tensor:
+    """Natural index k = k1 + n1*k2 of every element of rank's [n1/G, n2] output block (int64)."""
+    l1, l2 = fourstep_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << l2
+    r = n1 // world
+    k1 = torch.arange(rank * r, (rank + 1) * r, dtype=torch.int64).unsqueeze(1)
+    k2 = torch.arange(n2, dtype=torch.int64).unsqueeze(0)
+    return k1 + n1 * k2
+
+
+def fourstep_input_index(log_n: int, world: int, rank: int) -> torch.Tensor:
+    """Natural index j = j1*n2 + j2 of every element of rank's [n1, n2/G] input block (int64)."""
+    l1, l2 = fourstep_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << l2
+    c = n2 // world
+    j1 = torch.arange(n1, dtype=torch.int64).unsqueeze(1)
+    j2 = torch.arange(rank * c, (rank + 1) * c, dtype=torch.int64).unsqueeze(0)
+    return j1 * n2 + j2
+
+
+class HipLocalOps:
+    """Local stages on the GPU through the C ABI (contexts cached per size)."""
+
+    def __init__(self, log_n: int, device: torch.device):
+        from . import ntt as _ntt
+        self._ntt = _ntt
+        self.device = device
+        self.big = _ntt.NttContext(1 << log_n, device=device.index)
+        self._ctx = {}
+
+    def _ctx_for(self, m: int):
+        if m not in self._ctx:
+            self._ctx[m] = self._ntt.NttContext(m, device=self.device.index)
+        return self._ctx[m]
+
+    def ntt_rows(self, t: torch.Tensor, inverse: bool) -> None:
+        assert t.is_contiguous() and t.dtype == torch.int32 and t.dim() == 2
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._ctx_for(t.shape[1]).run_device(t.data_ptr(), t.data_ptr(), t.shape[0], inverse, stream=stream)
+
+    def twiddle(self, t: torch.Tensor, row0: int, inverse: bool) -> None:
+        from ._lib import check, lib
+        assert t.is_contiguous() and t.dtype == torch.int32 and t.dim() == 2
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.toyni_fourstep_twiddle_device(self.big.handle, t.data_ptr(), t.shape[0], t.shape[1], row0, int(inverse), stream or None),
+              "4-step twiddle failed")
+
+
+def _exchange(send: torch.Tensor, group=None) -> torch.Tensor:
+    """The one all-to-all: send[h] goes to rank h; returns recv with recv[g] from rank g."""
+    recv = torch.empty_like(send)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_to_all_single(recv, send, group=group)
+    else:
+        recv.copy_(send)
+    return recv
+
+
+def fourstep_forward(cols: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+    """cols: [n1, n2/G] int32 (element (j1, jc) = x[j1*n2 + rank*n2/G + jc]).  Returns [n1/G, n2] (see fourstep_output_index)."""
+    l1, l2 = fourstep_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << l2
+    c, r = n2 // world, n1 // world
+    assert cols.shape == (n1, c)
+    t = cols.t().contiguous()                      # [c, n1]: row = column j2 of the matrix
+    ops.ntt_rows(t, False)                         # n1-point transforms over j1
+    ops.twiddle(t, rank * c, False)                # * w_n^(j2 k1)
+    send = t.view(c, world, r).permute(1, 0, 2).contiguous()   # [G, c, r]: block h = k1 in rank h's chunk
+    recv = _exchange(send, group)                  # [G, c, r]: block g = j2 in rank g's chunk
+    rows = recv.permute(2, 0, 1).reshape(r, n2).contiguous()   # [k1_local, j2]
+    ops.ntt_rows(rows, False)                      # n2-point transforms over j2
+    return rows
+
+
+def fourstep_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+    """Mirror of fourstep_forward: [n1/G, n2] block of X -> [n1, n2/G] column block of x."""
+    l1, l2 = fourstep_split(log_n, world)
+    n1, n2 = 1 << l1, 1 << l2
+    c, r = n2 // world, n1 // world
+    assert rows.shape == (r, n2)
+    b = rows.contiguous().clone()
+    ops.ntt_rows(b, True)                          # inverse n2-point over k2 -> [k1_local, j2], scaled by n2^-1
+    send = b.view(r, world, c).permute(1, 2, 0).contiguous()   # [G, c, r]: block h = j2 in rank h's chunk
+    recv = _exchange(send, group)                  # [G, c, r]: block g = k1 in rank g's chunk
+    t = recv.permute(1, 0, 2).reshape(c, n1).contiguous()      # [jc, k1]
+    ops.twiddle(t, rank * c, True)                 # * w_n^-(j2 k1)
+    ops.ntt_rows(t, True)                          # inverse n1-point over k1, scaled by n1^-1
+    return t.t().contiguous()
