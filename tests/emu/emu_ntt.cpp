@@ -38,10 +38,11 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
     bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
         std::vector<uint32_t> lds(P::LDS_WORDS + 1, 0xDEADBEEFu);
-        for (uint64_t b = 0; b < nblocks; ++b) {
-            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, (uint32_t)b, tid, lds.data());
+        for (uint64_t v = 0; v < nblocks; ++v) {
+            const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);  // the persistent loop's virtual index -> tile
+            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, b, tid, lds.data());
             if constexpr (P::TWO_STEP) {
-                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, (uint32_t)b, tid, lds.data());
+                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
             }
         }
     });
@@ -64,6 +65,8 @@ static void test_field() {
         CHECK(bb_sub(a, b) == (uint32_t)orc_bb_sub(a, b), "sub %u %u", a, b);
         CHECK(mont_mul(bb_sub_lazy(a, b), to_mont(b)) == (uint32_t)orc_bb_mul(orc_bb_sub(a, b), b), "sub_lazy %u %u", a, b);
         CHECK(bb_halve(a) == (uint32_t)orc_bb_mul(a, BB_HALF), "halve %u", a);
+        if (b) CHECK(mont_dot_sub(a, (uint32_t)((a * 2654435761ull) % BB_P), to_mont(b), BB_P - to_mont(b)) ==
+                     (uint32_t)orc_bb_mul(orc_bb_sub(a, (a * 2654435761ull) % BB_P), b), "dot_sub %u %u", a, b);
         // lazy product accepts any u32 on the left
         uint32_t any = a * 2654435761u;
         CHECK(bb_reduce_2p(mont_mul_lazy(any, to_mont(b))) == (uint32_t)orc_bb_mul(any % BB_P, b), "lazy any %u %u", any, b);

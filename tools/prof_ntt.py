@@ -11,6 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TOYNI_HIP_RUNTIME", "system")  # torch-free driver: the ROCm install's own runtime
 import toyni_amd  # noqa: E402
 from toyni_amd._lib import check, lib  # noqa: E402
 

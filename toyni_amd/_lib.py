@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtoyni_hip.so")
+LIB_PATH = os.environ.get("TOYNI_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtoyni_hip.so")  # override: diagnostic builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -11,6 +11,29 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950). toyni_amd has no CPU path."
     )
 
+
+
+def _one_hip_runtime_per_process():
+    """libtoyni_hip.so needs libamdhip64.so.7.  A PyTorch-ROCm wheel bundles its OWN copy of that runtime (same
+    SONAME, different file); if ours binds to /opt/rocm's copy first and torch is imported later, the process ends up
+    with two HIP/HSA runtimes and the second one finds no GPU.  So when torch is installed, map its runtime first:
+    the dynamic loader then resolves our DT_NEEDED to it by SONAME, and a later `import torch` finds its own file
+    already mapped.  TOYNI_HIP_RUNTIME=system skips this (e.g. torch-free profiling drivers)."""
+    import importlib.util
+    import sys
+    if os.environ.get("TOYNI_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")  # locates the package, does not import it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
+_one_hip_runtime_per_process()
 lib = ctypes.CDLL(LIB_PATH)
 
 c_int = ctypes.c_int

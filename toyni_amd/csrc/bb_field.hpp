@@ -23,6 +23,27 @@
 #define TOYNI_DEV inline
 #endif
 
+// a value that is the same in every lane: on the device force it into an SGPR
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOYNI_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define TOYNI_UNIFORM(x) (x)
+#endif
+
+// scheduling fences (device only): TOYNI_SCHED_FENCE stops the instruction scheduler from moving anything across;
+// TOYNI_PIN(v) makes v opaque at this point so that a running product is not unrolled into many live values
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOYNI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define TOYNI_PIN(v) asm volatile("" : "+v"(v))
+// s_waitcnt vmcnt(0) alone (expcnt / lgkmcnt fields at their maxima), as a builtin so that the compiler's own
+// wait-count insertion knows every earlier VMEM operation has retired
+#define TOYNI_WAIT_VMEM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define TOYNI_SCHED_FENCE() ((void)0)
+#define TOYNI_PIN(v) ((void)0)
+#define TOYNI_WAIT_VMEM0() ((void)0)
+#endif
+
 namespace toyni {
 
 constexpr uint32_t BB_P = 2013265921u;          // src/babybear.rs:8
@@ -82,6 +103,18 @@ TOYNI_HD uint32_t mont_mul_lazy(uint32_t a, uint32_t bR) {
     return (uint32_t)(t >> 32);
 }
 TOYNI_HD uint32_t mont_mul(uint32_t a, uint32_t bR) { return bb_reduce_2p(mont_mul_lazy(a, bR)); }
+
+// (a - b) * w mod p as ONE Montgomery reduction of the two-term dot product a*wR + b*(p - wR):
+// a, b canonical, wR and nwR = p - wR canonical Montgomery forms (wR != 0).  The 64-bit sum stays below
+// 2 p^2, plus m*p below 2^32 p: < 2^64, quotient < 2p.  Saves the separate subtract of the butterfly
+// (integer multiply-adds issue at the add rate on gfx950, so a v_mad_u64_u32 is as cheap as a v_sub).
+TOYNI_HD uint32_t mont_dot_sub(uint32_t a, uint32_t b, uint32_t wR, uint32_t nwR) {
+    uint64_t t = (uint64_t)a * wR;
+    t += (uint64_t)b * nwR;
+    const uint32_t m = (uint32_t)t * BB_NPINV;
+    t += (uint64_t)m * BB_P;
+    return bb_reduce_2p((uint32_t)(t >> 32));
+}
 TOYNI_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, BB_R2); }
 TOYNI_HD uint32_t from_mont(uint32_t aR) { return mont_mul(aR, 1u); }
 

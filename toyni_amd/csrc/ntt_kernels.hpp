@@ -13,8 +13,9 @@
 //     y_p[prefix][k_p][j'] = w_{L_p}^(j' k_p) * sum_{j_p} y_{p-1}[prefix][j_p][j'] * w_{M_p}^(j_p k_p),
 //     L_p = M_p S_p.  The last pass has S_P = 1 (rows are contiguous) and scatters to natural order.
 //
-// One workgroup owns a tile of C columns (KIND_COL) or C rows (KIND_ROW_*) of one M-point
-// sub-transform and runs it in two register steps:
+// One workgroup owns tiles of C columns (KIND_COL) or C rows (KIND_ROW_*) of one M-point sub-transform; it is
+// persistent (loops over tiles, the next tile's HBM loads are in flight while the current one is finished) and
+// runs a tile in two register steps:
 //   step 1: each thread loads E1 = 2^LE1 elements straight from HBM into VGPRs (coalesced segments of
 //           C or E2 consecutive words), runs the LE1 high-bit radix-2 Gentleman-Sande stages in
 //           registers, and parks the tile in LDS;
@@ -48,12 +49,26 @@ struct PassArgs {
     uint64_t rows_total;       // KIND_ROW_N: number of rows (= batch); tiles may be ragged
 };
 
+// Diagnostic builds only (-DTOYNI_ABLATE=1|2|3, never the shipped library): bit 0 replaces tile loads by register
+// arithmetic, bit 1 makes tile stores conditional on a value that never occurs -- timing-only builds that price the
+// HBM side of a pass against its VALU/LDS side (results are garbage by construction).
+#ifndef TOYNI_ABLATE
+#define TOYNI_ABLATE 0
+#endif
+
 // base + 32-bit BYTE offset: keeps the address math in 32 bits so that global loads/stores take the
 // SGPR-base + VGPR-offset (+ immediate) form
 TOYNI_HD uint32_t ld32(const uint32_t* base, uint32_t byte_off) {
+#if TOYNI_ABLATE & 1
+    return (uint32_t)(reinterpret_cast<uintptr_t>(base) >> 2) + byte_off;
+#else
     return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
 }
 TOYNI_HD void st32(uint32_t* base, uint32_t byte_off, uint32_t v) {
+#if TOYNI_ABLATE & 2
+    if (v == 0xFFFFFFFFu)
+#endif
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
@@ -71,41 +86,62 @@ struct Pass {
     static constexpr uint32_t T = C * E2;          // threads per workgroup
     static constexpr uint32_t G2 = E1 / E2;        // step-2 groups per thread
     static constexpr bool TWO_STEP = LE2 > 0;
-    // LDS pitch of one tile row (KIND_ROW_*): breaks the power-of-two stride between rows
-    static constexpr uint32_t PITCH = KIND == KIND_ROW_T ? M + (C <= 16 ? 2 : 1) : M + (E2 & 31u);
-    static constexpr uint32_t LDS_WORDS = !TWO_STEP ? 0 : (KIND == KIND_COL ? M * C : C * PITCH);
 
-    // LDS word of tile element (c, r): c = column (KIND_COL) or row (KIND_ROW_*), r = position in the sub-transform
-    static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t r) {
-        if (KIND == KIND_COL) {
-            // [r][c]; with only 16 columns the bank is (r&1)*16 + c, so fold bit LE2 of r (lane-varying in
-            // step 2, constant per instruction in step 1) into bit 0
-            uint32_t rr = (C < 32) ? (r ^ ((r >> LE2) & 1u)) : r;
-            return rr * C + c;
-        } else {
-            // [c][r] with the low digit rotated by the high digit: step-1 writes (lanes = low digit) and
-            // step-2 reads (lanes = high digit) both spread over banks
-            uint32_t hi = r >> LE2;
-            uint32_t low = (r + hi) & (E2 - 1);
-            return c * PITCH + (hi << LE2) + low;
-        }
+    // ---- LDS tile layout -------------------------------------------------------------------------------
+    // Element (c, r) with r = hi * E2 + low.  Both layouts are LINEAR in (c, hi, low), so every LDS access of a
+    // thread is (one base register) + (compile-time immediate), and the pads make step-1 writes (lanes = c/low)
+    // and step-2 reads (lanes = c/hi) conflict-free in the 32-lane groups ds_read_b32 / ds_write_b32 are served in:
+    //   KIND_COL  : word = hi * (E2*C + PADC) + low * C + c       PADC = 16 when C = 16: bank = ((hi+low)&1)*16 + c
+    //   KIND_ROW_*: word = c * PITCH + hi * (E2 + 1) + low        hi stride 33 = 1 mod 32; PITCH spreads the rows
+    static constexpr uint32_t PADC = C < 32 ? 32 - C : 0;
+    static constexpr uint32_t HI_STRIDE = KIND == KIND_COL ? E2 * C + PADC : E2 + 1;
+    static constexpr uint32_t LOW_STRIDE = KIND == KIND_COL ? C : 1;
+    static constexpr uint32_t row_pitch() {
+        uint32_t base = E1 * (E2 + 1);
+        // residue of PITCH mod 32 that spreads the tile rows a 32-lane group touches in step 2
+        uint32_t want = KIND == KIND_ROW_T ? (C <= 16 ? 2u : 1u) : (E1 < 32 ? E1 : 0u);
+        return base + ((want + 32u - (base & 31u)) & 31u);
     }
+    static constexpr uint32_t PITCH = row_pitch();
+    static constexpr uint32_t C_STRIDE = KIND == KIND_COL ? 1 : PITCH;
+    static constexpr uint32_t LDS_WORDS = !TWO_STEP ? 0 : (KIND == KIND_COL ? E1 * HI_STRIDE : C * PITCH);
 
-    // A tile is addressed as (uniform 64-bit base pointer) + (32-bit per-thread element offset): every offset inside
-    // a tile is < n <= 2^27, so the loads/stores use the SGPR-base + VGPR-offset form and no 64-bit VALU address math.
+    // occupancy target: workgroups per CU by LDS (160 KiB), expressed as waves per SIMD for __launch_bounds__
+    // (capped at 4: with the prefetch pipeline 16 waves per CU hide the rest, and 128 VGPRs are needed)
+    static constexpr uint32_t lds_wg_per_cu() { return LDS_WORDS ? (160u * 1024u) / ((LDS_WORDS + (TWO_STEP ? M - E2 : 0u)) * 4u) : 8u; }
+    static constexpr uint32_t min_waves_per_simd() {
+        uint32_t w = (lds_wg_per_cu() * (T / 64u ? T / 64u : 1u) + 3u) / 4u;
+        return w < 1u ? 1u : (w > 4u ? 4u : w);
+    }
+    static constexpr uint32_t MIN_WAVES = min_waves_per_simd();
+
+    static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t hi, uint32_t low) { return c * C_STRIDE + hi * HI_STRIDE + low * LOW_STRIDE; }
+
+    // ---- tiles -----------------------------------------------------------------------------------------
+    // A tile is addressed as (uniform 64-bit base pointer) + (32-bit per-thread BYTE offset): every offset inside a
+    // tile is < 4n <= 2^29, so loads/stores take the SGPR-base + VGPR-offset form and no 64-bit VALU address math.
     struct Tile {
         const uint32_t* in;
         uint32_t* out;
-        uint32_t in_cshift_or_stride;       // KIND_ROW_T: log2 of the row stride; others unused
+        uint32_t row_shift;                 // KIND_ROW_T: log2 of the input row stride
         uint32_t col0;                      // KIND_COL: first column index j' of the tile
         uint32_t valid_c;                   // KIND_ROW_N: rows of this tile that exist
     };
+
+    // XCD-aware order: workgroups b and b+8 run on the same XCD (round-robin dispatch), and tiles 2x, 2x+1 share
+    // 128-byte lines (16 columns x 4 B = half a line), so within every 16 consecutive virtual indices the pair
+    // (2x, 2x+1) goes to workgroups x and x+8.  A bijection; placement only ever affects speed.
+    static TOYNI_HD uint32_t tile_order(uint32_t v, uint32_t ntiles) {
+        if ((ntiles & 15u) != 0) return v;
+        const uint32_t s = v & 15u;
+        return (v & ~15u) | ((s & 7u) << 1) | (s >> 3);
+    }
 
     static TOYNI_HD Tile tile_of(const PassArgs& a, uint32_t bid) {
         Tile t;
         t.col0 = 0;
         t.valid_c = C;
-        t.in_cshift_or_stride = 0;
+        t.row_shift = 0;
         if (KIND == KIND_COL) {
             const uint32_t tiles_log = a.log_S - LC;
             const uint64_t prefix = (uint64_t)bid >> tiles_log;
@@ -118,8 +154,8 @@ struct Pass {
             const uint32_t k1_tiles_log = a.log_M1 - LC;
             const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << LC;
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
-            t.in_cshift_or_stride = a.log_n - a.log_M1;
-            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.in_cshift_or_stride) + ((uint64_t)mid << LM));
+            t.row_shift = a.log_n - a.log_M1;
+            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM));
             t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
         } else {
             const uint64_t row0 = (uint64_t)bid << LC;
@@ -131,45 +167,81 @@ struct Pass {
         return t;
     }
 
-    // element offset of tile element (c, r) in the input
+    // element offset of tile element (c, r) in the input (linear in c and r)
     static TOYNI_HD uint32_t in_offset(const PassArgs& a, const Tile& t, uint32_t c, uint32_t r) {
         if (KIND == KIND_COL) return (r << a.log_S) + c;
-        if (KIND == KIND_ROW_T) return (c << t.in_cshift_or_stride) + r;
+        if (KIND == KIND_ROW_T) return (c << t.row_shift) + r;
         return (c << LM) + r;
     }
-    // element offset of finished element (c, natural sub-index k) in the output
+    // element offset of finished element (c, natural sub-index k) in the output (linear in c and k)
     static TOYNI_HD uint32_t out_offset(const PassArgs& a, uint32_t c, uint32_t k) {
         if (KIND == KIND_COL) return (k << a.log_S) + c;
         if (KIND == KIND_ROW_T) return c + (k << (a.log_n - LM));
         return (c << LM) + k;
     }
 
-    // w_L^e (Montgomery form, canonical) from the pass boundary's two-level table
-    static TOYNI_HD uint32_t boundary_tw(const PassArgs& a, uint32_t e) {
-        const uint32_t lo = a.tw_lo[e & ((1u << a.tw_lowbits) - 1)];
-        const uint32_t hi = a.tw_hi[e >> a.tw_lowbits];
-        return mont_mul(hi, lo);
+    // ---- thread coordinates ----------------------------------------------------------------------------
+    // step 1: KIND_COL lanes run over columns first (64-byte row segments), KIND_ROW_* over the contiguous row
+    static TOYNI_HD void coords1(uint32_t tid, uint32_t& c, uint32_t& lo) {
+        if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
+        else { lo = tid & (E2 - 1); c = tid >> LE2; }
+    }
+    // step 2, group g of the thread: lanes run over what is contiguous in the OUTPUT
+    static TOYNI_HD void coords2(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& hi) {
+        const uint32_t gamma = tid + g * T;
+        if (KIND == KIND_ROW_N) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
+        else { c = gamma & (C - 1); hi = gamma >> LC; }
     }
 
-    // Finish and store the NB = 2^LB elements a thread holds for one (c, khi): register i holds natural sub-index
-    // k = (bitrev(i) << LSH) | khi.  KIND_COL multiplies by the inter-pass twiddle w_L^(j' k) = A * G^bitrev(i) with
-    // A = w_L^(j' khi), G = w_L^(j' << LSH): two table lookups per thread and one running product, instead of a
-    // gather per element (the inverse's n^-1, a.scale on the first pass, is folded into A).
+    // KIND_COL inter-pass twiddle of a step-2 group: w_L^(j' k) with k = (b << LSH) | khi is A * G^b,
+    // A = w_L^(j' khi) (times n^-1 on the first pass of an inverse), G = w_L^(j' << LSH): two table lookups per
+    // group and a running product instead of a gather per element.  The lookups are split into an issue half (the
+    // four table words) and a finish half, so the persistent kernel can issue them a tile ahead.
+    struct Twiddle { uint32_t a0, g; };
+    struct TwiddleRaw { uint32_t a_lo, a_hi, g_lo, g_hi; };
+    template <int LSH>
+    static TOYNI_HD TwiddleRaw group_twiddle_issue(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi) {
+        TwiddleRaw r{0u, 0u, 0u, 0u};
+        if (KIND == KIND_COL) {
+            const uint32_t jcol = t.col0 + c;
+            const uint32_t mask = (1u << a.tw_lowbits) - 1u;
+            const uint32_t ea = jcol * khi, eg = jcol << LSH;   // < L <= 2^27
+            r.a_lo = a.tw_lo[ea & mask];
+            r.a_hi = a.tw_hi[ea >> a.tw_lowbits];
+            r.g_lo = a.tw_lo[eg & mask];
+            r.g_hi = a.tw_hi[eg >> a.tw_lowbits];
+        }
+        return r;
+    }
+    static TOYNI_HD Twiddle group_twiddle_finish(const PassArgs& a, const TwiddleRaw& r) {
+        Twiddle tw{0u, 0u};
+        if (KIND == KIND_COL) {
+            tw.a0 = mont_mul(r.a_hi, r.a_lo);
+            if (a.scale) tw.a0 = mont_mul(tw.a0, a.scale);
+            tw.g = mont_mul(r.g_hi, r.g_lo);
+        }
+        return tw;
+    }
+    template <int LSH>
+    static TOYNI_HD Twiddle group_twiddle(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi) {
+        return group_twiddle_finish(a, group_twiddle_issue<LSH>(a, t, c, khi));
+    }
+
+    // Finish and store the NB = 2^LB elements held for one (c, khi): register i holds natural sub-index
+    // k = (bitrev(i) << LSH) | khi.
     template <int LB, int LSH>
-    static TOYNI_HD void finish(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi, uint32_t (&x)[1 << LB]) {
+    static TOYNI_HD void finish(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi, Twiddle twd, uint32_t (&x)[1 << LB]) {
         constexpr uint32_t NB = 1u << LB;
         // out_offset is linear in k: element b sits at off0 + b * step (bytes)
         const uint32_t off0 = out_offset(a, c, khi) << 2;
         const uint32_t step = (out_offset(a, 0u, 1u << LSH) - out_offset(a, 0u, 0u)) << 2;
+        char* base = reinterpret_cast<char*>(t.out);
         if (KIND == KIND_COL) {
-            const uint32_t jcol = t.col0 + c;
-            uint32_t tw = boundary_tw(a, jcol * khi);
-            if (a.scale) tw = mont_mul(tw, a.scale);
-            const uint32_t g = boundary_tw(a, jcol << LSH);
+            uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                st32(t.out, off0 + b * step, mont_mul(x[cx_bitrev(b, LB)], tw));
-                if (b + 1 < NB) tw = mont_mul(tw, g);
+                st32(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
+                if (b + 1 < NB) { tw = mont_mul(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else {
             const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
@@ -177,80 +249,144 @@ struct Pass {
             for (uint32_t b = 0; b < NB; ++b) {
                 uint32_t v = x[cx_bitrev(b, LB)];
                 if (scaled) v = mont_mul(v, a.scale);
-                st32(t.out, off0 + b * step, v);
+                st32(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, v);
             }
         }
     }
 
-    // LE bits of radix-2 DIF butterflies on x[0..2^LE), register index bit s <-> sub-transform bit s + shift.
-    // `low` = the thread's bits below `shift` (0 when the stage twiddles are wave-uniform).
+    // LE bits of radix-2 DIF butterflies on x[0..2^LE), register index bit s <-> sub-transform bit s + SHIFT.
+    // Twiddle of the butterfly (i, i + 2^s): w_{2^(t+1)}^(low + q 2^SHIFT), t = s + SHIFT, q = i mod 2^s.
+    //   SHIFT > 0: per-thread (`low` = the thread's bits below SHIFT), read from `tw1` = the packed stage table from
+    //              stage SHIFT on (the persistent kernel keeps that slice in LDS: reads count on lgkmcnt, so they
+    //              never wait behind the previous tile's HBM stores the way a vmcnt load would);
+    //   SHIFT = 0: the same for every thread -> `uni` holds the top stage's 2^(LE-1) twiddles in SGPRs (the lower
+    //              stages reuse them at a stride), and the q = 0 butterflies have twiddle 1 (plain subtract).
     template <int LE, int SHIFT>
-    static TOYNI_HD void stages(uint32_t (&x)[1 << LE], const uint32_t* stage_tw, uint32_t low) {
+    static TOYNI_HD void stages(uint32_t (&x)[1 << LE], const uint32_t* tw1, uint32_t low, const uint32_t* uni) {
 #pragma unroll
         for (int s = LE - 1; s >= 0; --s) {
             const int d = 1 << s;
             const int t = s + SHIFT;  // butterfly spans 2^(t+1) elements
-            const uint32_t* tw = stage_tw + ((1u << t) - 1u) + low;
-            uint32_t w[1 << (LE - 1)];
+            uint32_t w[1 << (LE - 1)], nw[1 << (LE - 1)];
 #pragma unroll
-            for (int q = 0; q < d; ++q) w[q] = tw[(uint32_t)q << SHIFT];
+            for (int q = 0; q < d; ++q) {
+                // a lower stage's twiddles are a stride of the top stage's: w_{2^(t+1)}^q = w_{2^LE}^(q << (LE-1-t))
+                w[q] = SHIFT == 0 ? uni[(uint32_t)q << (LE - 1 - s)] : tw1[(1u << t) - (1u << SHIFT) + low + ((uint32_t)q << SHIFT)];
+                nw[q] = BB_P - w[q];
+            }
 #pragma unroll
             for (int i = 0; i < (1 << LE); ++i) {
                 if (i & d) continue;
                 const uint32_t u = x[i], v = x[i + d];
                 x[i] = bb_add(u, v);
-                if (SHIFT == 0 && (i & (d - 1)) == 0) x[i + d] = bb_sub(u, v);  // twiddle w^0 = 1 (known at compile time)
-                else x[i + d] = mont_mul(bb_sub_lazy(u, v), w[i & (d - 1)]);
+                if (SHIFT == 0 && (i & (d - 1)) == 0) x[i + d] = bb_sub(u, v);
+                else x[i + d] = mont_dot_sub(u, v, w[i & (d - 1)], nw[i & (d - 1)]);
             }
         }
     }
 
-    static TOYNI_HD void phase1(const PassArgs& a, uint32_t bid, uint32_t tid, uint32_t* lds) {
-        const Tile t = tile_of(a, bid);
-        uint32_t c, lo;
-        if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
-        else { lo = tid & (E2 - 1); c = tid >> LE2; }
-        const bool live = KIND != KIND_ROW_N || c < t.valid_c;  // only single-pass row tiles can be ragged
+    // step-1 slice of the packed stage table: stages LE2 .. LM-1 = words [2^LE2 - 1, 2^LM - 1)
+    static constexpr uint32_t TW1_WORDS = TWO_STEP ? M - E2 : 0;
+    static TOYNI_HD const uint32_t* tw1_global(const PassArgs& a) { return a.stage_tw + (E2 - 1u); }
 
-        uint32_t x[E1];
+    // the wave-uniform twiddles of the last LU stage bits: w_{2^LU}^q, q < 2^(LU-1) = stage LU-1 of the packed table
+    static constexpr int LU = TWO_STEP ? LE2 : LE1;
+    static constexpr uint32_t NU = 1u << (LU - 1);
+    struct Uniform { uint32_t w[NU]; };
+    static TOYNI_HD Uniform load_uniform(const PassArgs& a) {
+        Uniform u;
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) u.w[q] = TOYNI_UNIFORM(a.stage_tw[NU - 1u + q]);
+        return u;
+    }
+
+    // ---- the pieces of a pass, in the order a workgroup runs them ---------------------------------------
+    // (a) HBM -> registers: E1 elements of the thread's column / row, r = lo + i * E2
+    //     (registers [I0, I1) only: the persistent kernel prefetches a leading part of the next tile)
+    template <uint32_t I0 = 0, uint32_t I1 = E1>
+    static TOYNI_HD void load_tile(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1]) {
+        uint32_t c, lo;
+        coords1(tid, c, lo);
+        const bool live = KIND != KIND_ROW_N || c < t.valid_c;  // only single-pass row tiles can be ragged
         // in_offset is linear in r: register i sits at off0 + i * step (bytes)
         const uint32_t off0 = in_offset(a, t, c, lo) << 2;
         const uint32_t step = (in_offset(a, t, 0u, E2) - in_offset(a, t, 0u, 0u)) << 2;
+        // register i: (uniform base + i * uniform step) + one per-thread offset -> SGPR pointer math, a single VGPR
+        const char* base = reinterpret_cast<const char*>(t.in);
         if (live) {
 #pragma unroll
-            for (uint32_t i = 0; i < E1; ++i) x[i] = ld32(t.in, off0 + i * step);
+            for (uint32_t i = I0; i < I1; ++i) x[i] = ld32(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0);
         } else {
 #pragma unroll
-            for (uint32_t i = 0; i < E1; ++i) x[i] = 0u;
-        }
-
-        stages<LE1, LE2>(x, a.stage_tw, lo);
-
-        if (TWO_STEP) {
-#pragma unroll
-            for (uint32_t i = 0; i < E1; ++i) lds[lds_word(c, lo + (i << LE2))] = x[i];
-        } else {
-            if (live) finish<LE1, 0>(a, t, c, 0u, x);
+            for (uint32_t i = I0; i < I1; ++i) x[i] = 0u;
         }
     }
 
-    static TOYNI_HD void phase2(const PassArgs& a, uint32_t bid, uint32_t tid, const uint32_t* lds) {
-        const Tile t = tile_of(a, bid);
+    // (b) the LE1 high-bit stages in registers, then park the tile in LDS (two-step) or finish (single-step)
+    static TOYNI_HD void step1(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1], uint32_t* lds, const Uniform& uni,
+                               const uint32_t* tw1) {
+        uint32_t c, lo;
+        coords1(tid, c, lo);
+        stages<LE1, LE2>(x, tw1, lo, uni.w);
+        if (TWO_STEP) {
+            const uint32_t base = lds_word(c, 0u, lo);
+#pragma unroll
+            for (uint32_t i = 0; i < E1; ++i) lds[base + i * HI_STRIDE] = x[i];
+        } else {
+            if (KIND != KIND_ROW_N || c < t.valid_c) finish<LE1, 0>(a, t, c, 0u, group_twiddle<0>(a, t, c, 0u), x);
+        }
+    }
+
+    // (c) inter-pass twiddle seeds of the thread's step-2 groups: table lookups, issued early (see the kernel)
+    struct SeedsRaw { TwiddleRaw g[G2 ? G2 : 1]; };
+    struct Seeds { Twiddle g[G2 ? G2 : 1]; };
+    static TOYNI_HD SeedsRaw seeds_issue(const PassArgs& a, const Tile& t, uint32_t tid) {
+        SeedsRaw s;
 #pragma unroll
         for (uint32_t g = 0; g < G2; ++g) {
-            const uint32_t gamma = tid + g * T;
             uint32_t c, hi;
-            if (KIND == KIND_ROW_N) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
-            else { c = gamma & (C - 1); hi = gamma >> LC; }
-
-            uint32_t x[E2];
-#pragma unroll
-            for (uint32_t i = 0; i < E2; ++i) x[i] = lds[lds_word(c, (hi << LE2) + i)];
-
-            stages<LE2, 0>(x, a.stage_tw, 0u);
-
-            if (KIND != KIND_ROW_N || c < t.valid_c) finish<LE2, LE1>(a, t, c, bitrev32(hi, LE1), x);
+            coords2(tid, g, c, hi);
+            s.g[g] = group_twiddle_issue<LE1>(a, t, c, bitrev32(hi, LE1));
         }
+        return s;
+    }
+    static TOYNI_HD Seeds seeds_finish(const PassArgs& a, const SeedsRaw& r) {
+        Seeds s;
+#pragma unroll
+        for (uint32_t g = 0; g < G2; ++g) s.g[g] = group_twiddle_finish(a, r.g[g]);
+        return s;
+    }
+
+    // (d) after the barrier: LDS -> registers, the LE2 low-bit stages (wave-uniform twiddles), twiddle, HBM store
+    static TOYNI_HD void step2(const PassArgs& a, const Tile& t, uint32_t tid, const uint32_t* lds, const Seeds& seeds, const Uniform& uni) {
+#pragma unroll
+        for (uint32_t g = 0; g < G2; ++g) {
+            uint32_t c, hi;
+            coords2(tid, g, c, hi);
+            uint32_t x[E2];
+            const uint32_t base = lds_word(c, hi, 0u);
+#pragma unroll
+            for (uint32_t i = 0; i < E2; ++i) x[i] = lds[base + i * LOW_STRIDE];
+            stages<LE2, 0>(x, nullptr, 0u, uni.w);
+            // Persistent kernel: the next tile's prefetch (and seed lookups) were issued before this point and have had
+            // the whole of step 2 so far to land.  Retire them HERE, while no store of this tile is outstanding yet:
+            // vmcnt retires in issue order, so any later wait for them would also wait for the 32 stores below.
+            if (g == 0) TOYNI_WAIT_VMEM0();
+            if (KIND != KIND_ROW_N || c < t.valid_c) finish<LE2, LE1>(a, t, c, bitrev32(hi, LE1), seeds.g[g], x);
+        }
+    }
+
+    // Whole tile, one thread, in program order (single-step kinds; tests/emu runs the two-step kinds as
+    // phase1 for every thread, then phase2 for every thread -- the pass' one data barrier).
+    static TOYNI_HD void phase1(const PassArgs& a, uint32_t tile_id, uint32_t tid, uint32_t* lds) {
+        const Tile t = tile_of(a, tile_id);
+        uint32_t x[E1];
+        load_tile(a, t, tid, x);
+        step1(a, t, tid, x, lds, load_uniform(a), tw1_global(a));
+    }
+    static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
+        const Tile t = tile_of(a, tile_id);
+        step2(a, t, tid, lds, seeds_finish(a, seeds_issue(a, t, tid)), load_uniform(a));
     }
 };
 

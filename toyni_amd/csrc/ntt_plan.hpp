@@ -124,6 +124,12 @@ inline bool build_plan(int log_n, NttPlan& plan) {
 
 // (kind, log_m) -> Pass<...> instantiation.  This table is the single place that fixes the step split and
 // the tile width of every pass shape; f receives a value of the Pass type.
+// tile width of the 1024-point passes: 32 columns / rows = whole 128-byte lines per row segment (one 1024-thread
+// workgroup per CU, 132 KiB of LDS); 16 = half lines, two 512-thread workgroups per CU
+#ifndef TOYNI_LC10
+#define TOYNI_LC10 5
+#endif
+
 template <class F>
 inline bool dispatch_pass(int kind, int log_m, F&& f) {
 #define TOYNI_PASS_CASE(K, A, B, LC_) \
@@ -133,14 +139,14 @@ inline bool dispatch_pass(int kind, int log_m, F&& f) {
     TOYNI_PASS_CASE(KIND_COL, 4, 3, 5)
     TOYNI_PASS_CASE(KIND_COL, 4, 4, 5)
     TOYNI_PASS_CASE(KIND_COL, 5, 4, 5)
-    TOYNI_PASS_CASE(KIND_COL, 5, 5, 4)
+    TOYNI_PASS_CASE(KIND_COL, 5, 5, TOYNI_LC10)
     // last pass of a multi-pass transform: contiguous rows in, transposed (natural order) out
     TOYNI_PASS_CASE(KIND_ROW_T, 5, 0, 6)
     TOYNI_PASS_CASE(KIND_ROW_T, 3, 3, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 4, 3, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 4, 4, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 5, 4, 5)
-    TOYNI_PASS_CASE(KIND_ROW_T, 5, 5, 4)
+    TOYNI_PASS_CASE(KIND_ROW_T, 5, 5, TOYNI_LC10)
     // single-pass transforms (n <= 1024): one row per batch entry
     TOYNI_PASS_CASE(KIND_ROW_N, 1, 0, 6)
     TOYNI_PASS_CASE(KIND_ROW_N, 2, 0, 6)

@@ -24,13 +24,60 @@ using namespace toyni;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <class P>
-__global__ void __launch_bounds__(P::T) ntt_pass_kernel(const PassArgs a) {
-    __shared__ uint32_t lds[P::LDS_WORDS ? P::LDS_WORDS : 1];
-    P::phase1(a, blockIdx.x, threadIdx.x, lds);
-    if constexpr (P::TWO_STEP) {
+// Persistent workgroups: workgroup b runs tiles tile_order(b), tile_order(b + grid), ...  Two-step passes are
+// software-pipelined around one rule: vmcnt retires loads AND stores in issue order, so a load that is waited for
+// after a tile's 32 HBM stores were issued would wait for those stores to be acknowledged.  Hence, in the steady state,
+//   * the step-1 stage twiddles live in LDS (copied once per workgroup; LDS reads count on lgkmcnt),
+//   * as soon as a tile's registers are parked in LDS they are refilled with the NEXT tile's HBM loads (first PF of
+//     them; the rest at the top of the next iteration), and the next tile's twiddle-seed lookups are issued right
+//     behind them -- all of it BEFORE the current tile's stores, in flight across the barrier and the whole of step 2.
+// The barriers are raw s_barrier with an explicit LDS-only wait: __syncthreads() would also drain vmcnt.
+template <class P, int PF>
+__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const PassArgs a, const uint32_t ntiles) {
+    __shared__ uint32_t lds[(P::LDS_WORDS + P::TW1_WORDS) ? (P::LDS_WORDS + P::TW1_WORDS) : 1];
+    const uint32_t tid = threadIdx.x;
+    if constexpr (!P::TWO_STEP) {
+        for (uint32_t v = blockIdx.x; v < ntiles; v += gridDim.x) P::phase1(a, P::tile_order(v, ntiles), tid, lds);
+    } else {
+        constexpr uint32_t NPF = PF < 0 ? 0u : ((uint32_t)PF > P::E1 ? P::E1 : (uint32_t)PF);
+        uint32_t v = blockIdx.x;
+        if (v >= ntiles) return;
+        uint32_t* lds_tw1 = lds + P::LDS_WORDS;
+        uint32_t x[P::E1];
+        typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
+        P::template load_tile<0, NPF>(a, t, tid, x);
+        typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
+        const typename P::Uniform uni = P::load_uniform(a);  // step-2 twiddles, SGPR-resident for the whole loop
+        for (uint32_t j = tid; j < P::TW1_WORDS; j += P::T) lds_tw1[j] = P::tw1_global(a)[j];
+        TOYNI_WAIT_VMEM0();  // the first tile's loads have landed: the loop is entered with no load pending on any path
         __syncthreads();
-        P::phase2(a, blockIdx.x, threadIdx.x, lds);
+        while (true) {
+            P::template load_tile<NPF, P::E1>(a, t, tid, x);
+            P::step1(a, t, tid, x, lds, uni, lds_tw1);
+            typename P::Seeds seeds = P::seeds_finish(a, raw);
+#pragma unroll
+            for (uint32_t g = 0; g < P::G2; ++g) { TOYNI_PIN(seeds.g[g].a0); TOYNI_PIN(seeds.g[g].g); }  // materialised HERE
+            TOYNI_SCHED_FENCE();
+            const uint32_t vn = v + gridDim.x;
+            const bool more = vn < ntiles;  // uniform
+            typename P::Tile tn = t;
+            if (more) {
+                tn = P::tile_of(a, P::tile_order(vn, ntiles));
+                P::template load_tile<0, NPF>(a, tn, tid, x);  // prefetch
+                raw = P::seeds_issue(a, tn, tid);              // and the next tile's seed lookups, still ahead of the stores
+            }
+            TOYNI_SCHED_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
+            __builtin_amdgcn_s_barrier();
+            TOYNI_SCHED_FENCE();
+            P::step2(a, t, tid, lds, seeds, uni);
+            if (!more) break;
+            TOYNI_SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();  // every wave has its step-2 LDS reads in registers before the tile is overwritten
+            TOYNI_SCHED_FENCE();
+            t = tn;
+            v = vn;
+        }
     }
 }
 
@@ -173,6 +220,7 @@ struct toyni_ntt_ctx {
     uint64_t* d_stage64 = nullptr;   // H2D / D2H staging on the reference's u64 layout
     size_t stage64_elems = 0;
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
+    int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
     std::mutex mu;
 };
@@ -202,6 +250,43 @@ int grid_for(size_t items, int block = 256) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// prefetch depth variants (TOYNI_PREFETCH = 0 | 8 | 16 | 32; tuning knob, default chosen from measurements)
+static int g_prefetch = -1;
+static int prefetch_depth() {
+    if (g_prefetch < 0) {
+        g_prefetch = 32;
+        if (const char* env = std::getenv("TOYNI_PREFETCH")) g_prefetch = std::atoi(env);
+    }
+    return g_prefetch;
+}
+
+template <class P>
+void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
+    switch (prefetch_depth()) {
+        case 0: hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
+        case 8: hipLaunchKernelGGL((ntt_pass_kernel<P, 8>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
+        case 32: hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
+        default: hipLaunchKernelGGL((ntt_pass_kernel<P, 16>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
+    }
+}
+
+// Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
+// count; TOYNI_WG_PER_CU overrides the occupancy query (tuning knob).
+template <class P>
+unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
+    static int per_cu = 0;  // per instantiation
+    if (per_cu == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0) != hipSuccess || occ < 1) occ = 1;
+        if (const char* env = std::getenv("TOYNI_WG_PER_CU")) { int v = std::atoi(env); if (v > 0) occ = v; }
+        per_cu = occ;
+    }
+    uint64_t g = (uint64_t)c->num_cus * (uint64_t)per_cu;
+    if (g > ntiles) g = ntiles;
+    if (g >= 16) g &= ~(uint64_t)15;  // keep the XCD pairing of tile_order aligned across loop iterations
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
 // enqueue the passes of `batch` transforms; d_in == d_out allowed
 int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s) {
     if (batch == 0) return 0;
@@ -228,7 +313,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                 [&](auto pass, const PassArgs& a, uint64_t nblocks) {
                                     using P = decltype(pass);
                                     if (err != hipSuccess) return;
-                                    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);
+                                    launch_pass<P>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
                                     err = hipGetLastError();
                                 });
         if (!ok) return TOYNI_E_INVALID_SIZE;
@@ -320,6 +405,10 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     c->device = device;
     if (!build_plan(ilog2(n), c->plan)) { delete c; return TOYNI_E_INVALID_SIZE; }
     if (const char* env = std::getenv("TOYNI_CHUNK_ELEMS")) c->chunk_elems = (size_t)std::strtoull(env, nullptr, 0);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     auto fail = [&](hipError_t e) { toyni_ntt_ctx_destroy(c); return (int)e; };
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
@@ -579,10 +668,10 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
                             [&](auto pass, const PassArgs& a, uint64_t nblocks) {
                                 using P = decltype(pass);
                                 if (err != hipSuccess) return;
-                                hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);  // warm
+                                const unsigned grid = persistent_grid<P>(c, nblocks);
+                                launch_pass<P>(grid, s, a, (uint32_t)nblocks);  // warm
                                 (void)hipEventRecord(e0, s);
-                                for (int r = 0; r < reps; ++r)
-                                    hipLaunchKernelGGL(ntt_pass_kernel<P>, dim3((unsigned)nblocks), dim3(P::T), 0, s, a);
+                                for (int r = 0; r < reps; ++r) launch_pass<P>(grid, s, a, (uint32_t)nblocks);
                                 (void)hipEventRecord(e1, s);
                                 err = hipEventSynchronize(e1);
                                 float ms = 0.f;
