@@ -162,9 +162,20 @@ def main():
         # batch, so its share is 8 * n * batch / npass.
         alg_bytes = 8.0 * n * batch / npass
         achieved = alg_bytes / (fwd_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("log_n") == args.log_n and tj.get("batch_per_gpu") == batch:
+                # PMC numbers cannot be collected inside this process; this is the committed rocprofv3 measurement of the
+                # same command (tools/collect_profiles.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the dominant kernel
+                want = "Pass<0" if dom == 0 else "Pass<1"
+                for k, v in tj["kernels"].items():
+                    if want in k:
+                        traffic, traffic_src = v["hbm_bytes_per_launch"], f"profiles/r01_traffic.json ({k.split('(')[0]})"
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "kernel": f"ntt_pass_kernel pass {dom} of {npass} (forward)", "kernel_ms": fwd_ms[dom],
             "algorithmic_bytes_per_launch": alg_bytes,
             "all_pass_ms": {"forward": fwd_ms, "inverse": inv_ms},

@@ -151,9 +151,10 @@ int main(int argc, char** argv) {
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }
-    for (int i = 2; i < argc; ++i) {                // extra sizes (2-pass 2^20, 3-pass 2^21..)
+    for (int i = 2; i < argc; ++i) {                // extra sizes "LOG" or "LOGxBATCH" (2-pass 2^20, 3-pass 2^21.., wide tiles)
         int log_n = std::atoi(argv[i]);
-        test_ntt(log_n, 1, 0);
+        const char* xb = std::strchr(argv[i], 'x');
+        test_ntt(log_n, xb ? (uint64_t)std::atoll(xb + 1) : 1, 0);
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }

@@ -8,7 +8,8 @@ import __graft_entry__ as entry
 
 def test_kernel_bodies_match_oracle_on_cpu():
     exe = entry.build_emu()
-    # sizes 2^0..2^14 (1- and 2-pass), plus 2^20 (the 1024 x 1024 headline split) and 2^21 (3-pass)
-    res = subprocess.run([exe, "14", "20", "21"], capture_output=True, text=True, timeout=600)
+    # sizes 2^0..2^14 (1- and 2-pass), plus 2^20 (the 1024 x 1024 headline split; 8-wide tiles at batch 1, 16-wide at
+    # batch 4, 32-wide at batch 16 -- the streaming configuration) and 2^21 (3-pass)
+    res = subprocess.run([exe, "14", "20", "20x4", "20x16", "21"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root: rocprofv3 passes over the SAME command bench.py is judged on.
+#   1. --kernel-trace --stats          -> per-kernel average duration (must agree with bench.py's HIP-event number)
+#   2. --pmc FETCH_SIZE / WRITE_SIZE   -> HBM traffic per launch (separate passes; TCC slots do not fit both)
+#   3. --pmc SQ_* / GRBM_GUI_ACTIVE    -> VALU issue, waits, effective clock
+# Summaries land in gpurun_out/profiles_<tag>/ ; tools/summarize_profiles.py turns them into the files under profiles/.
+set -u
+TAG=${1:-r01}
+BATCH=${2:-1024}
+OUT=gpurun_out/profiles_$TAG
+mkdir -p $OUT
+CMD="python3 bench.py --steps 3 --warmup 1 --batch $BATCH --no-extras --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $CMD > $OUT/sq.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/lds -- $CMD > $OUT/lds.log 2>&1 || exit 1
+grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
+echo "profiles collected in $OUT"

@@ -1,0 +1,89 @@
+// Memory-pattern probe (diagnostic, not part of the library): what HBM rate do the NTT passes' access patterns
+// reach with no arithmetic at all?  Build: hipcc --offload-arch=gfx950 -O3 -o build/membench tools/membench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+// contiguous 16 B / lane copy
+__global__ void copy16(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) out[i] = in[i];
+}
+// contiguous 4 B / lane copy
+__global__ void copy4(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+// column tile: tile = C columns x M rows of a [M][S] matrix (row stride ld words); 32 elements per thread, like the pass.
+// mode 0: read strided, write same place (in-place layout, other buffer); mode 1: read strided only (sum -> rare store); mode 2: write strided only
+template <int C, int MODE>
+__global__ void __launch_bounds__(1024) coltile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t ntiles, uint32_t log_s, uint32_t ld, uint32_t M) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = tid % C, lo = tid / C;
+    const uint32_t rows_per_iter = blockDim.x / C;  // 32
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t tiles_per = (1u << log_s) / C;
+        const size_t base = (size_t)(t / tiles_per) * M * ld + (size_t)(t % tiles_per) * C;
+        uint32_t x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const size_t off = base + (size_t)(lo + i * rows_per_iter) * ld + c;
+            if (MODE != 2) x[i] = in[off]; else x[i] = tid + i;
+        }
+        if (MODE == 1) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s ^= x[i];
+            if (s == 0xDEADBEEF) out[base + tid] = s;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) out[base + (size_t)(lo + i * rows_per_iter) * ld + c] = x[i] + 1;
+        }
+    }
+}
+
+template <class F> float timeit(F f, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main() {
+    const size_t n = (size_t)1 << 28;  // 1 GiB of u32
+    uint32_t *in, *out;
+    CK(hipMalloc(&in, n * 4 + (64 << 20))); CK(hipMalloc(&out, n * 4 + (64 << 20)));
+    CK(hipMemset(in, 1, n * 4)); CK(hipMemset(out, 2, n * 4));
+    float ms;
+    ms = timeit([&] { hipLaunchKernelGGL(copy16, dim3(2048), dim3(256), 0, 0, (const uint4*)in, (uint4*)out, n / 4); }, 10);
+    printf("copy16 contiguous           : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL(copy4, dim3(2048), dim3(256), 0, 0, in, out, n); }, 10);
+    printf("copy4 contiguous            : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    const uint32_t M = 1024, log_s = 10;
+    for (int grid : {256, 512}) {
+        const uint32_t nt32 = (uint32_t)(n / (M * 32)), nt16 = (uint32_t)(n / (M * 16));
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<32, 0>), dim3(grid), dim3(1024), 0, 0, in, out, nt32, log_s, 1024u, M); }, 10);
+        printf("coltile C=32 r+w  grid %4d  : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<32, 1>), dim3(grid), dim3(1024), 0, 0, in, out, nt32, log_s, 1024u, M); }, 10);
+        printf("coltile C=32 read grid %4d  : %.3f ms  %.2f TB/s\n", grid, ms, 1.0 * n * 4 / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<32, 2>), dim3(grid), dim3(1024), 0, 0, in, out, nt32, log_s, 1024u, M); }, 10);
+        printf("coltile C=32 write grid %4d : %.3f ms  %.2f TB/s\n", grid, ms, 1.0 * n * 4 / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<16, 0>), dim3(grid * 2), dim3(512), 0, 0, in, out, nt16, log_s, 1024u, M); }, 10);
+        printf("coltile C=16 r+w  grid %4d  : %.3f ms  %.2f TB/s\n", grid * 2, ms, 2.0 * n * 4 / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<64, 0>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (512 * 64)), log_s, 1024u, 512u); }, 10);
+        printf("coltile C=64 M=512 r+w %4d  : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+    }
+    // padded leading dimension: rows 4 KB + 128 B apart (breaks the power-of-two stride)
+    {
+        const uint32_t ld = 1024 + 32;
+        const uint32_t nt32 = (uint32_t)((n / ld / M) * 32);  // whole matrices only
+        ms = timeit([&] { hipLaunchKernelGGL((coltile<32, 0>), dim3(256), dim3(1024), 0, 0, in, out, nt32, log_s, ld, M); }, 10);
+        printf("coltile C=32 r+w ld=1056    : %.3f ms  %.2f TB/s\n", ms, 2.0 * (double)nt32 * M * 32 * 4 / ms / 1e9);
+    }
+    return 0;
+}

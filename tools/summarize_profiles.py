@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profiles_<tag>/ (tools/collect_profiles.sh) into the tracked summaries under profiles/:
+  profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats table, verbatim
+  profiles/<tag>_counters.json         mean per dispatch of every collected counter, per kernel
+  profiles/<tag>_traffic.json          HBM bytes per launch of each NTT pass kernel:
+                                       (2 * FETCH_SIZE + WRITE_SIZE) * 1024  -- FETCH_SIZE is in KiB and on gfx950 reports
+                                       half of a coalesced stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+bench.py reads <tag>_traffic.json for roofline.traffic when its workload matches."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+src = f"gpurun_out/profiles_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def counters(sub):
+    files = glob.glob(f"{src}/{sub}/*/*counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": len(next(iter(cs.values())))} for k, cs in agg.items()}
+
+
+stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
+allc = {}
+for sub in ("fetch", "write", "sq", "lds"):
+    for k, v in counters(sub).items():
+        allc.setdefault(k, {}).update(v)
+json.dump(allc, open(f"profiles/{tag}_counters.json", "w"), indent=1, sort_keys=True)
+
+durations = {}
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        durations[r["Name"]] = float(r["AverageNs"])
+traffic = {"log_n": 20, "batch_per_gpu": batch, "command": f"python3 bench.py --steps 3 --warmup 1 --batch {batch} --no-extras --no-cpu-baseline",
+           "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "kernels": {}}
+for k, v in allc.items():
+    if "ntt_pass_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        traffic["kernels"][k] = {
+            "fetch_size_kib_raw": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"],
+            "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+            "rocprof_avg_ns": durations.get(k),
+        }
+json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
+bj = f"{src}/bench_under_rocprof.json"
+if os.path.exists(bj) and os.path.getsize(bj):
+    shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof.json")
+print(json.dumps(traffic, indent=1)[:1500])

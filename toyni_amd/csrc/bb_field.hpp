@@ -38,10 +38,13 @@
 // s_waitcnt vmcnt(0) alone (expcnt / lgkmcnt fields at their maxima), as a builtin so that the compiler's own
 // wait-count insertion knows every earlier VMEM operation has retired
 #define TOYNI_WAIT_VMEM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+// s_waitcnt vmcnt(N): everything but the N youngest VMEM operations has retired (N <= 63, compile-time)
+#define TOYNI_WAIT_VMEM_ALLOW(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 0xF) | (((N) >> 4) << 14))
 #else
 #define TOYNI_SCHED_FENCE() ((void)0)
 #define TOYNI_PIN(v) ((void)0)
 #define TOYNI_WAIT_VMEM0() ((void)0)
+#define TOYNI_WAIT_VMEM_ALLOW(N) ((void)0)
 #endif
 
 namespace toyni {

@@ -368,10 +368,6 @@ struct Pass {
 #pragma unroll
             for (uint32_t i = 0; i < E2; ++i) x[i] = lds[base + i * LOW_STRIDE];
             stages<LE2, 0>(x, nullptr, 0u, uni.w);
-            // Persistent kernel: the next tile's prefetch (and seed lookups) were issued before this point and have had
-            // the whole of step 2 so far to land.  Retire them HERE, while no store of this tile is outstanding yet:
-            // vmcnt retires in issue order, so any later wait for them would also wait for the 32 stores below.
-            if (g == 0) TOYNI_WAIT_VMEM0();
             if (KIND != KIND_ROW_N || c < t.valid_c) finish<LE2, LE1>(a, t, c, bitrev32(hi, LE1), seeds.g[g], x);
         }
     }

@@ -124,29 +124,36 @@ inline bool build_plan(int log_n, NttPlan& plan) {
 
 // (kind, log_m) -> Pass<...> instantiation.  This table is the single place that fixes the step split and
 // the tile width of every pass shape; f receives a value of the Pass type.
-// tile width of the 1024-point passes: 32 columns / rows = whole 128-byte lines per row segment (one 1024-thread
-// workgroup per CU, 132 KiB of LDS); 16 = half lines, two 512-thread workgroups per CU
-#ifndef TOYNI_LC10
-#define TOYNI_LC10 5
-#endif
-
+//
+// The 1024-point passes come in three tile widths.  32 columns / rows = whole 128-byte lines per row segment (one
+// 1024-thread workgroup per CU, 132 KiB of LDS): the streaming choice, +12 % over 16-wide on the batched workload.
+// But a tile is 32 K elements, so a SINGLE 2^20 transform is only 32 tiles; when the launch has too few tiles to
+// cover the chip the narrower variants (16 / 8 wide) are used -- the data is cache-resident at that size anyway.
+// `log_tiles32` = log2 of the number of 32-wide tiles the launch would have.
 template <class F>
-inline bool dispatch_pass(int kind, int log_m, F&& f) {
+inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f) {
 #define TOYNI_PASS_CASE(K, A, B, LC_) \
     if (kind == K && log_m == (A) + (B)) { f(Pass<K, A, B, LC_>{}); return true; }
+#define TOYNI_PASS_CASE_W(K, A, B)                                                    \
+    if (kind == K && log_m == (A) + (B)) {                                             \
+        if (log_tiles32 >= 9) f(Pass<K, A, B, 5>{});                                   \
+        else if (log_tiles32 >= 7) f(Pass<K, A, B, 4>{});                              \
+        else f(Pass<K, A, B, 3>{});                                                    \
+        return true;                                                                   \
+    }
     // strided column passes (first / middle passes of a 2- or 3-pass transform)
     TOYNI_PASS_CASE(KIND_COL, 3, 3, 5)
     TOYNI_PASS_CASE(KIND_COL, 4, 3, 5)
     TOYNI_PASS_CASE(KIND_COL, 4, 4, 5)
     TOYNI_PASS_CASE(KIND_COL, 5, 4, 5)
-    TOYNI_PASS_CASE(KIND_COL, 5, 5, TOYNI_LC10)
+    TOYNI_PASS_CASE_W(KIND_COL, 5, 5)
     // last pass of a multi-pass transform: contiguous rows in, transposed (natural order) out
     TOYNI_PASS_CASE(KIND_ROW_T, 5, 0, 6)
     TOYNI_PASS_CASE(KIND_ROW_T, 3, 3, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 4, 3, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 4, 4, 5)
     TOYNI_PASS_CASE(KIND_ROW_T, 5, 4, 5)
-    TOYNI_PASS_CASE(KIND_ROW_T, 5, 5, TOYNI_LC10)
+    TOYNI_PASS_CASE_W(KIND_ROW_T, 5, 5)
     // single-pass transforms (n <= 1024): one row per batch entry
     TOYNI_PASS_CASE(KIND_ROW_N, 1, 0, 6)
     TOYNI_PASS_CASE(KIND_ROW_N, 2, 0, 6)
@@ -159,6 +166,7 @@ inline bool dispatch_pass(int kind, int log_m, F&& f) {
     TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 4)
     TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
 #undef TOYNI_PASS_CASE
+#undef TOYNI_PASS_CASE_W
     return false;
 }
 
@@ -186,7 +194,13 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         a.log_M1 = (uint32_t)plan.pass[0].log_m;
         a.log_mid = (uint32_t)(plan.log_n - plan.pass[0].log_m - pp.log_m);
         a.rows_total = batch;
-        bool ok = dispatch_pass(pp.kind, pp.log_m, [&](auto pass) {
+        // number of 32-wide tiles this launch would have (decides the tile width of the 1024-point passes)
+        int log_tiles32 = 0;
+        {
+            const uint64_t tiles32 = (batch << (total_log - (uint64_t)pp.log_m)) >> 5;
+            while ((2ull << log_tiles32) <= tiles32) ++log_tiles32;
+        }
+        bool ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) {
             using P = decltype(pass);
             uint64_t nblocks;
             if (pp.kind == KIND_ROW_N) nblocks = (batch + P::C - 1) / P::C;

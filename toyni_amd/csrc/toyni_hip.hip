@@ -32,6 +32,10 @@ using namespace toyni;
 //     them; the rest at the top of the next iteration), and the next tile's twiddle-seed lookups are issued right
 //     behind them -- all of it BEFORE the current tile's stores, in flight across the barrier and the whole of step 2.
 // The barriers are raw s_barrier with an explicit LDS-only wait: __syncthreads() would also drain vmcnt.
+template <class P> struct PassKindOf;
+template <int K, int A, int B, int C> struct PassKindOf<Pass<K, A, B, C>> { static constexpr int value = K; };
+template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
+
 template <class P, int PF>
 __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const PassArgs a, const uint32_t ntiles) {
     __shared__ uint32_t lds[(P::LDS_WORDS + P::TW1_WORDS) ? (P::LDS_WORDS + P::TW1_WORDS) : 1];
@@ -52,6 +56,13 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
         TOYNI_WAIT_VMEM0();  // the first tile's loads have landed: the loop is entered with no load pending on any path
         __syncthreads();
         while (true) {
+            // The tile's loads (prefetch + seed lookups) were issued BEFORE the previous tile's E1 stores, and vmcnt
+            // retires in issue order: allowing exactly the E1 youngest operations to stay outstanding retires every
+            // load while the stores keep draining in the background.  (Ragged single-pass row tiles issue fewer
+            // stores, so they wait for everything.)
+            static_assert(P::G2 * P::E2 == P::E1 && P::E1 <= 63, "stores per tile per thread");
+            if constexpr (kind_of<P>() != KIND_ROW_N) TOYNI_WAIT_VMEM_ALLOW(P::E1);
+            else TOYNI_WAIT_VMEM0();
             P::template load_tile<NPF, P::E1>(a, t, tid, x);
             P::step1(a, t, tid, x, lds, uni, lds_tw1);
             typename P::Seeds seeds = P::seeds_finish(a, raw);
@@ -250,7 +261,7 @@ int grid_for(size_t items, int block = 256) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// prefetch depth variants (TOYNI_PREFETCH = 0 | 8 | 16 | 32; tuning knob, default chosen from measurements)
+// prefetch variants (TOYNI_PREFETCH = 0 | 32: none / the whole next tile; tuning knob, 32 is the measured default)
 static int g_prefetch = -1;
 static int prefetch_depth() {
     if (g_prefetch < 0) {
@@ -262,12 +273,8 @@ static int prefetch_depth() {
 
 template <class P>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
-    switch (prefetch_depth()) {
-        case 0: hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
-        case 8: hipLaunchKernelGGL((ntt_pass_kernel<P, 8>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
-        case 32: hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
-        default: hipLaunchKernelGGL((ntt_pass_kernel<P, 16>), dim3(grid), dim3(P::T), 0, s, a, ntiles); break;
-    }
+    if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
 }
 
 // Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
