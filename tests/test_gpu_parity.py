@@ -20,6 +20,11 @@ pytestmark = pytest.mark.gpu
 def ta():
     import __graft_entry__ as entry
     entry.build_hip()
+    # torch (used by the 4-step tests for device tensors) brings its own copy of the HIP runtime: initialise it FIRST,
+    # as bench.py does, so that the whole session runs on one runtime whose device state was set up once, up front
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    torch.cuda.init()
     import toyni_amd
     assert toyni_amd.gpu_available(), "GPU tests need a device"
     return toyni_amd
