@@ -110,6 +110,13 @@ int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint
 /* Host-slice form of the same (u64 elements, blocking): out has len/2 elements. */
 int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, uint64_t beta);
 
+/* Extension-field codewords, fri_fold_ext (src/math/fri.rs:7-25): values and beta in Ext = F_p[X]/(X^4 - 11)
+ * (src/ext.rs), points in the base field.  Elements are AoS: 4 consecutive words c0..c3 (u32 on the device, u64 on
+ * the host = #[repr(C)] Ext { c: [BabyBear; 4] }).  m / len count ELEMENTS.  beta = 4 canonical coordinates. */
+int toyni_fri_fold_ext_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, uint32_t* d_out, size_t m, const uint32_t beta[4], uint32_t x0, void* stream);
+int toyni_fri_fold_ext_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint32_t* d_out, size_t m, const uint32_t beta[4], void* stream);
+int toyni_fri_fold_ext_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, const uint64_t beta[4]);
+
 /* ------------------------------------------------------------------------------------------------
  * 4. Plumbing
  * ---------------------------------------------------------------------------------------------- */

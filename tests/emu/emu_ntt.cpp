@@ -25,6 +25,7 @@ void orc_fill_splitmix(uint64_t*, size_t, uint64_t);
 void orc_fill_pattern_7i3(uint64_t*, size_t);
 int orc_fri_fold(uint64_t*, const uint64_t*, size_t, const uint64_t*, uint64_t);
 int orc_domain_elements(uint64_t*, size_t, uint64_t);
+int orc_fri_fold_ext(uint64_t*, const uint64_t*, size_t, const uint64_t*, const uint64_t*);
 }
 
 using namespace toyni;
@@ -140,6 +141,26 @@ static void test_fold(int log_N, int layer, uint32_t shift) {
     CHECK(bad == 0, "fold log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
 }
 
+static void test_fold_ext(size_t len) {
+    const size_t half = len / 2;
+    std::vector<uint64_t> evals(4 * len), xs(len), want(4 * half);
+    orc_fill_splitmix(evals.data(), 4 * len, 4242);
+    orc_domain_elements(xs.data(), len, 7);
+    const uint64_t beta[4] = {123456789ull, 987654321ull, 5ull, BB_P - 1ull};
+    orc_fri_fold_ext(want.data(), evals.data(), len, xs.data(), beta);
+    uint32_t bh[4];
+    for (int k = 0; k < 4; ++k) bh[k] = bb_mul_host((uint32_t)beta[k], BB_HALF);
+    const ExtFactor f = ext_factor_host(bh);
+    size_t bad = 0;
+    for (size_t i = 0; i < half; ++i) {
+        Ext4 a, b;
+        for (int k = 0; k < 4; ++k) { a.c[k] = (uint32_t)evals[4 * i + k]; b.c[k] = (uint32_t)evals[4 * (i + half) + k]; }
+        const Ext4 r = fold_ext_one(a, b, to_mont_host(bb_inv_host((uint32_t)xs[i])), f);
+        for (int k = 0; k < 4; ++k) if (r.c[k] != (uint32_t)want[4 * i + k]) ++bad;
+    }
+    CHECK(bad == 0, "fold_ext len=%zu: %zu mismatches", len, bad);
+}
+
 int main(int argc, char** argv) {
     int max_log = argc > 1 ? std::atoi(argv[1]) : 16;
     test_field();
@@ -163,6 +184,9 @@ int main(int argc, char** argv) {
     test_fold(13, 12, 7);
     test_fold(1, 0, 7);
     test_fold(6, 2, 1);
+    test_fold_ext(2);
+    test_fold_ext(64);
+    test_fold_ext(1024);
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
     return failures ? 1 : 0;
 }

@@ -484,3 +484,36 @@ def test_fourstep_2_27_equals_single_device_transform(ta):
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint32)                     # [k1][k2] -> X[k1 + n1 k2]
     assert (got.T.reshape(-1) == direct).all()
+
+
+# ---------------------------------------------------------------- Ext-valued fold (src/math/fri.rs:7-25)
+@pytest.mark.parametrize("m", [2, 8, 1024, 1 << 15])
+def test_fold_ext_vs_oracle(ta, m):
+    rng = np.random.default_rng(m)
+    evals = rng.integers(0, P, size=(m, 4)).astype(np.uint64)
+    xs = oracle.domain_elements(m, 7)
+    beta = [int(v) for v in rng.integers(0, P, size=4)]
+    want = oracle.fri_fold_ext(evals, xs, beta)
+    assert (ta.fri_fold_ext(evals, xs, beta) == want).all()                       # explicit points, host form
+    # structured points, device-resident
+    ctx = ta.ntt.get_or_create_ctx(max(m, 2))
+    a, o = DevBuf(ta, m * 16), DevBuf(ta, m * 8)
+    a.upload(evals.astype(np.uint32))
+    ta.fri_fold_ext_device(ctx, a.ptr, o.ptr, m, beta, 7)
+    ctx.synchronize()
+    got = o.download(np.uint32, (m // 2) * 4).reshape(-1, 4)
+    a.free(); o.free()
+    assert (got == want).all()
+
+
+def test_fold_ext_embeds_base_fold(ta):
+    # a base codeword embedded in Ext with a base beta folds to the embedded base fold
+    m = 256
+    evals = oracle.splitmix(m, 9)
+    xs = oracle.domain_elements(m, 7)
+    e4 = np.zeros((m, 4), dtype=np.uint64)
+    e4[:, 0] = evals
+    out = ta.fri_fold_ext(e4, xs, [424242, 0, 0, 0])
+    assert (out[:, 0] == oracle.fri_fold(evals, xs, 424242)).all() and not out[:, 1:].any()
+    with pytest.raises(AssertionError, match="even"):
+        ta.fri_fold_ext(np.zeros((3, 4), dtype=np.uint64), np.ones(3, dtype=np.uint64), [1, 0, 0, 0])

@@ -76,6 +76,9 @@ SIGNATURES = {
     "toyni_fri_fold_layers_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_fri_fold_xs_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_void_p]),
     "toyni_fri_fold_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_u64]),
+    "toyni_fri_fold_ext_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_u32, c_void_p]),
+    "toyni_fri_fold_ext_xs_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
+    "toyni_fri_fold_ext_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
     # section 4
     "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
     "toyni_free": (c_int, [c_void_p]),

@@ -118,6 +118,14 @@ TOYNI_HD uint32_t mont_dot_sub(uint32_t a, uint32_t b, uint32_t wR, uint32_t nwR
     t += (uint64_t)m * BB_P;
     return bb_reduce_2p((uint32_t)(t >> 32));
 }
+// a*bR + c*dR as one Montgomery reduction (a, c canonical; bR, dR canonical Montgomery forms): same bound as above
+TOYNI_HD uint32_t mont_dot2(uint32_t a, uint32_t bR, uint32_t c, uint32_t dR) {
+    uint64_t t = (uint64_t)a * bR;
+    t += (uint64_t)c * dR;
+    const uint32_t m = (uint32_t)t * BB_NPINV;
+    t += (uint64_t)m * BB_P;
+    return bb_reduce_2p((uint32_t)(t >> 32));
+}
 TOYNI_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, BB_R2); }
 TOYNI_HD uint32_t from_mont(uint32_t aR) { return mont_mul(aR, 1u); }
 

@@ -413,6 +413,43 @@ TOYNI_HD uint32_t fold_one(const FoldArgs& f, uint64_t i, uint32_t a, uint32_t b
     return bb_add(avg, mont_mul(bb_sub_lazy(a, b), cw));
 }
 
+// ---- Ext = F_p[X]/(X^4 - 11) (src/ext.rs), only what fri_fold_ext needs ----
+struct Ext4 { uint32_t c[4]; };
+// The fixed right-hand factor of an Ext product, prepared once: coordinates in Montgomery form plus 11 * coordinates
+// (X^4 = 11 folds the high half of the schoolbook product back, src/ext.rs:178-192).
+struct ExtFactor { uint32_t b[4], b11[4]; };
+inline ExtFactor ext_factor_host(const uint32_t beta[4]) {
+    ExtFactor f;
+    for (int k = 0; k < 4; ++k) { f.b[k] = to_mont_host(beta[k]); f.b11[k] = to_mont_host(bb_mul_host(beta[k], 11u)); }
+    return f;
+}
+// a (plain canonical coordinates) * f  ->  plain canonical coordinates; four 2-term dot products per coordinate pair
+TOYNI_HD Ext4 ext_mul(const Ext4& a, const ExtFactor& f) {
+    Ext4 r;
+    r.c[0] = bb_add(mont_dot2(a.c[0], f.b[0], a.c[1], f.b11[3]), mont_dot2(a.c[2], f.b11[2], a.c[3], f.b11[1]));
+    r.c[1] = bb_add(mont_dot2(a.c[0], f.b[1], a.c[1], f.b[0]), mont_dot2(a.c[2], f.b11[3], a.c[3], f.b11[2]));
+    r.c[2] = bb_add(mont_dot2(a.c[0], f.b[2], a.c[1], f.b[1]), mont_dot2(a.c[2], f.b[0], a.c[3], f.b11[3]));
+    r.c[3] = bb_add(mont_dot2(a.c[0], f.b[3], a.c[1], f.b[2]), mont_dot2(a.c[2], f.b[1], a.c[3], f.b[0]));
+    return r;
+}
+
+// fri_fold_ext (src/math/fri.rs:7-25): out = (a+b)/2 + ((a-b)/2 * beta) * x^-1 coordinate-wise avg/diff, Ext product with beta.
+// `scaleR` = Montgomery form of the base-field factor applied to (a-b): x^-1 (times whatever the caller folded in);
+// `f` = ExtFactor of beta/2.
+TOYNI_HD Ext4 fold_ext_one(const Ext4& a, const Ext4& b, uint32_t scaleR, const ExtFactor& f) {
+    Ext4 d, avg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        avg.c[k] = bb_halve(bb_add(a.c[k], b.c[k]));
+        d.c[k] = mont_mul(bb_sub_lazy(a.c[k], b.c[k]), scaleR);
+    }
+    const Ext4 p = ext_mul(d, f);
+    Ext4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.c[k] = bb_add(avg.c[k], p.c[k]);
+    return r;
+}
+
 // ---- FRI fold with explicit points (the reference's signature fri_fold(evals, xs, beta)) ----
 // x^-1 by Fermat like src/babybear.rs:111-114, shared over BATCH elements with Montgomery's trick.
 TOYNI_HD uint32_t bb_mul_plain(uint32_t a, uint32_t b) { return mont_mul(a, to_mont(b)); }

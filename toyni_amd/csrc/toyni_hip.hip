@@ -182,6 +182,59 @@ __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __rest
     }
 }
 
+// FRI fold over Ext values (src/math/fri.rs:7-25), AoS 4 x u32 per element = one 16-byte access per lane.
+// Structured points x_i = x0 * w_m^i: scale_i = x0^-1 * w_m^-i from the ctx' inverse-root table.
+struct FoldExtArgs {
+    FoldArgs base;      // evals/out count ELEMENTS of 4 words; base.coef = Montgomery form of x0^-1
+    ExtFactor beta_half;
+};
+__global__ void __launch_bounds__(256) fri_fold_ext_kernel(const FoldExtArgs fa) {
+    const FoldArgs& f = fa.base;
+    const uint64_t half = f.half;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint4* ea = reinterpret_cast<const uint4*>(f.evals);
+    const uint4* eb = ea + half;
+    uint4* o = reinterpret_cast<uint4*>(f.out);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
+        const uint32_t e = (uint32_t)(i << f.log_step);
+        const uint32_t w = mont_mul(f.inv_hi[e >> f.lowbits], f.inv_lo[e & ((1u << f.lowbits) - 1)]);
+        const uint32_t scaleR = mont_mul(w, f.coef);
+        const uint4 a = ea[i], b = eb[i];
+        const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, scaleR, fa.beta_half);
+        o[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
+    }
+}
+
+// explicit base-field points (the reference's signature fri_fold_ext(evals, xs, beta))
+__global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __restrict__ evals, const uint32_t* __restrict__ xs,
+                                                               uint4* __restrict__ out, uint64_t half, const ExtFactor beta_half) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t groups = (half + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
+        uint32_t x[4], pre[4];
+        uint32_t acc = 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = 4 * q + j;
+            x[j] = i < half ? xs[i] : 1u;
+            pre[j] = acc;
+            acc = bb_mul_plain(acc, x[j]);
+        }
+        uint32_t inv = bb_inv_dev(acc);
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const uint64_t i = 4 * q + j;
+            const uint32_t xinv = bb_mul_plain(inv, pre[j]);
+            inv = bb_mul_plain(inv, x[j]);
+            if (i < half) {
+                const uint4 a = evals[i], b = evals[i + half];
+                const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, to_mont(xinv), beta_half);
+                out[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
+            }
+        }
+    }
+}
+
 // instruction-throughput probe (8 independent chains per lane)
 template <int WHICH>
 __global__ void __launch_bounds__(256) microbench_kernel(uint32_t seed, int iters, uint32_t* sink) {
@@ -596,6 +649,82 @@ int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint
     const uint32_t beta_half_R = to_mont_host(bb_mul_host(beta, BB_HALF));
     hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
     return (int)hipGetLastError();
+}
+
+static bool ext_beta_half(const uint32_t beta[4], ExtFactor* out) {
+    uint32_t bh[4];
+    for (int k = 0; k < 4; ++k) {
+        if (beta[k] >= BB_P) return false;
+        bh[k] = bb_mul_host(beta[k], BB_HALF);
+    }
+    *out = ext_factor_host(bh);
+    return true;
+}
+
+int toyni_fri_fold_ext_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, const uint32_t beta[4], uint32_t x0, void* stream) {
+    if (!c || !d_evals || !d_out || !beta) return TOYNI_E_NULL;
+    if (m % 2) return TOYNI_E_ODD_LENGTH;
+    if (m == 0) return TOYNI_OK;
+    if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
+    if (x0 == 0) return TOYNI_E_ZERO_INVERSE;
+    FoldExtArgs fa{};
+    if (x0 >= BB_P || !ext_beta_half(beta, &fa.beta_half)) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    fa.base.evals = d_evals;
+    fa.base.out = d_out;
+    fa.base.inv_lo = c->d_inv + c->plan.dom_lo_off;
+    fa.base.inv_hi = c->d_inv + c->plan.dom_hi_off;
+    fa.base.lowbits = c->plan.dom_lowbits;
+    fa.base.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
+    fa.base.coef = to_mont_host(bb_inv_host(x0));
+    fa.base.half = m / 2;
+    hipLaunchKernelGGL(fri_fold_ext_kernel, dim3(grid_for(fa.base.half)), dim3(256), 0, (hipStream_t)stream, fa);
+    return (int)hipGetLastError();
+}
+
+int toyni_fri_fold_ext_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint32_t* d_out, size_t m, const uint32_t beta[4], void* stream) {
+    if (!d_evals || !d_xs || !d_out || !beta) return TOYNI_E_NULL;
+    if (m % 2) return TOYNI_E_ODD_LENGTH;
+    if (m == 0) return TOYNI_OK;
+    ExtFactor f;
+    if (!ext_beta_half(beta, &f)) return TOYNI_E_RANGE;
+    const uint64_t half = m / 2;
+    hipLaunchKernelGGL(fri_fold_ext_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(d_evals), d_xs, reinterpret_cast<uint4*>(d_out), half, f);
+    return (int)hipGetLastError();
+}
+
+int toyni_fri_fold_ext_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, const uint64_t beta[4]) {
+    if (!h_out || !h_evals || !h_xs || !beta) return TOYNI_E_NULL;
+    if (len % 2) return TOYNI_E_ODD_LENGTH;  // src/math/fri.rs:8
+    if (len == 0) return TOYNI_OK;
+    const size_t half = len / 2;
+    std::vector<uint32_t> e32(4 * len), x32(half), o32(4 * half);
+    for (size_t i = 0; i < 4 * len; ++i) e32[i] = (uint32_t)(h_evals[i] % BB_P);
+    for (size_t i = 0; i < half; ++i) {
+        x32[i] = (uint32_t)(h_xs[i] % BB_P);
+        if (x32[i] == 0) return TOYNI_E_ZERO_INVERSE;
+    }
+    uint32_t b32[4];
+    for (int k = 0; k < 4; ++k) b32[k] = (uint32_t)(beta[k] % BB_P);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    uint32_t *d_e = nullptr, *d_x = nullptr, *d_o = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_e); (void)hipFree(d_x); (void)hipFree(d_o); };
+#define FOLD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
+    FOLD_TRY(hipMalloc((void**)&d_e, e32.size() * sizeof(uint32_t)));
+    FOLD_TRY(hipMalloc((void**)&d_x, half * sizeof(uint32_t)));
+    FOLD_TRY(hipMalloc((void**)&d_o, o32.size() * sizeof(uint32_t)));
+    FOLD_TRY(hipMemcpy(d_e, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FOLD_TRY(hipMemcpy(d_x, x32.data(), half * sizeof(uint32_t), hipMemcpyHostToDevice));
+    int rc = toyni_fri_fold_ext_xs_device(d_e, d_x, d_o, len, b32, nullptr);
+    if (rc) { cleanup(); return rc; }
+    FOLD_TRY(hipMemcpy(o32.data(), d_o, o32.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+#undef FOLD_TRY
+    cleanup();
+    for (size_t i = 0; i < o32.size(); ++i) h_out[i] = o32[i];
+    return TOYNI_OK;
 }
 
 int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, uint64_t beta) {

@@ -28,3 +28,24 @@ def fri_fold_layers_device(ctx, d_evals: int, d_layers: int, betas, shift: int, 
     b = np.ascontiguousarray(betas, dtype=np.uint32)
     check(lib.toyni_fri_fold_layers_device(ctx.handle, d_evals, d_layers, b.ctypes.data, b.size, shift, stream or None),
           "GPU FRI fold failed")
+
+
+def fri_fold_ext(evals4, xs, beta4) -> np.ndarray:
+    """src/math/fri.rs:7-25: Ext values [len, 4] and beta (4 coordinates), base-field points; returns [len/2, 4]."""
+    e = np.ascontiguousarray(evals4, dtype=np.uint64).reshape(-1, 4)
+    x = np.ascontiguousarray(xs, dtype=np.uint64)
+    b = np.ascontiguousarray(beta4, dtype=np.uint64)
+    assert e.shape[0] % 2 == 0, "Evaluations length must be even"  # src/math/fri.rs:8
+    assert x.size >= e.shape[0] // 2 and b.size == 4
+    out = np.empty((e.shape[0] // 2, 4), dtype=np.uint64)
+    st = lib.toyni_fri_fold_ext_host(out.ctypes.data, e.ctypes.data, e.shape[0], x.ctypes.data, b.ctypes.data)
+    assert st != 10005, "Cannot invert zero"
+    check(st, "GPU FRI fold (Ext) failed")
+    return out
+
+
+def fri_fold_ext_device(ctx, d_evals: int, d_out: int, m: int, beta4, x0: int, stream: int = 0) -> None:
+    """Device-resident Ext fold of one layer of m elements (4 packed u32 each) on the points x0 * w_m^i."""
+    b = np.ascontiguousarray(beta4, dtype=np.uint32)
+    assert b.size == 4
+    check(lib.toyni_fri_fold_ext_device(ctx.handle, d_evals, d_out, m, b.ctypes.data, x0, stream or None), "GPU FRI fold (Ext) failed")
