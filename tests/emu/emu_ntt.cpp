@@ -26,6 +26,8 @@ void orc_fill_pattern_7i3(uint64_t*, size_t);
 int orc_fri_fold(uint64_t*, const uint64_t*, size_t, const uint64_t*, uint64_t);
 int orc_domain_elements(uint64_t*, size_t, uint64_t);
 int orc_fri_fold_ext(uint64_t*, const uint64_t*, size_t, const uint64_t*, const uint64_t*);
+int orc_domain_fft(uint64_t*, size_t, const uint64_t*, size_t, uint64_t);
+int orc_domain_ifft(uint64_t*, size_t, uint64_t);
 }
 
 using namespace toyni;
@@ -33,8 +35,17 @@ using namespace toyni;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
-static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch) {
+static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1) {
     const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
+    std::vector<uint32_t> cblob;
+    CosetTables cs;
+    if (shift != 1 && plan.log_n > 0) {
+        uint32_t lo_off, hi_off;
+        cs.s = inverse ? bb_inv_host(shift) : shift;
+        append_two_level(cblob, plan.log_n, cs.s, 1u, lo_off, hi_off, cs.lowbits);
+        cs.lo = cblob.data() + lo_off;
+        cs.hi = cblob.data() + hi_off;
+    }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
     bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
@@ -46,8 +57,32 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
                 for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
             }
         }
-    });
+    }, cs);
     CHECK(ok, "no pass instantiation for log_n=%d", plan.log_n);
+}
+
+// BabyBearDomain::fft / ifft on a coset (src/math/domain.rs:85-123) with the scaling fused into the passes
+static void test_coset(int log_n, uint64_t batch, uint32_t shift) {
+    NttPlan plan;
+    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    const size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> ref(n * batch), want(n * batch);
+    orc_fill_splitmix(ref.data(), n * batch, 0xC05E7ull + log_n);
+    std::vector<uint32_t> in(n * batch), work(n * batch), out(n * batch);
+    for (size_t i = 0; i < n * batch; ++i) in[i] = (uint32_t)ref[i];
+    for (uint64_t b = 0; b < batch; ++b) orc_domain_fft(want.data() + b * n, n, ref.data() + b * n, n, shift);
+    emu_transform(plan, false, in.data(), work.data(), out.data(), batch, shift);
+    size_t bad = 0;
+    for (size_t i = 0; i < n * batch; ++i) if (out[i] != (uint32_t)want[i]) ++bad;
+    CHECK(bad == 0, "coset fft log_n=%d batch=%llu: %zu mismatches", log_n, (unsigned long long)batch, bad);
+    // ifft of the same input (as evaluations), in place
+    want = ref;
+    for (uint64_t b = 0; b < batch; ++b) orc_domain_ifft(want.data() + b * n, n, shift);
+    std::vector<uint32_t> buf = in;
+    emu_transform(plan, true, buf.data(), work.data(), buf.data(), batch, shift);
+    bad = 0;
+    for (size_t i = 0; i < n * batch; ++i) if (buf[i] != (uint32_t)want[i]) ++bad;
+    CHECK(bad == 0, "coset ifft log_n=%d batch=%llu: %zu mismatches", log_n, (unsigned long long)batch, bad);
 }
 
 static void test_field() {
@@ -169,6 +204,7 @@ int main(int argc, char** argv) {
         test_ntt(log_n, 1, 0);
         test_ntt(log_n, log_n <= 10 ? 70 : 3, 0);   // ragged row tiles for the single-pass kinds
         if (log_n == 8) test_ntt(log_n, 1, 1);      // src/ntt.rs:263-287 input
+        test_coset(log_n, log_n <= 10 ? 5 : 2, 7);  // COSET_SHIFT = 7, src/fibonacci.rs:16
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }
@@ -176,6 +212,7 @@ int main(int argc, char** argv) {
         int log_n = std::atoi(argv[i]);
         const char* xb = std::strchr(argv[i], 'x');
         test_ntt(log_n, xb ? (uint64_t)std::atoll(xb + 1) : 1, 0);
+        if (!xb) test_coset(log_n, 1, 1234567891u);
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }

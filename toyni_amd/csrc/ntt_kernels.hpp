@@ -47,6 +47,16 @@ struct PassArgs {
     uint32_t log_M1;           // KIND_ROW_T: log2 M_1 (k_1 range the tile rows run over)
     uint32_t log_mid;          // KIND_ROW_T: log2(n / (M_1 * M)) -- number of middle digits (1 for P = 2)
     uint64_t rows_total;       // KIND_ROW_N: number of rows (= batch); tiles may be ragged
+    // Fused coset scaling of BabyBearDomain (src/math/domain.rs:154-174), replacing the host's serial shift^i loop:
+    // cs_mode 1 = multiply INPUT element j of every transform by s^j (first pass of a forward coset FFT),
+    // cs_mode 2 = multiply OUTPUT element k by s^k (last pass of an inverse one, s = shift^-1); 0 = off.
+    // cs_lo/cs_hi: two-level table of s^x, x < n (Montgomery); cs_g: Montgomery form of the power of s between two
+    // consecutive registers of a thread (uniform per launch, computed by the host for the pass shape).
+    const uint32_t* cs_lo;
+    const uint32_t* cs_hi;
+    uint32_t cs_lowbits;
+    uint32_t cs_mode;
+    uint32_t cs_g;
 };
 
 // Diagnostic builds only (-DTOYNI_ABLATE=1|2|3, never the shipped library): bit 0 replaces tile loads by register
@@ -82,6 +92,7 @@ template <int KIND, int LE1, int LE2, int LC>
 struct Pass {
     static_assert(LE2 <= LE1 && LE1 <= 5 && LE1 >= 1, "step sizes");
     static constexpr int LM = LE1 + LE2;
+    static constexpr int LE1_ = LE1;
     static constexpr uint32_t M = 1u << LM, E1 = 1u << LE1, E2 = 1u << LE2, C = 1u << LC;
     static constexpr uint32_t T = C * E2;          // threads per workgroup
     static constexpr uint32_t G2 = E1 / E2;        // step-2 groups per thread
@@ -125,6 +136,7 @@ struct Pass {
         uint32_t* out;
         uint32_t row_shift;                 // KIND_ROW_T: log2 of the input row stride
         uint32_t col0;                      // KIND_COL: first column index j' of the tile
+        uint32_t out0;                      // in-transform index of output (c = 0, k = 0): KIND_ROW_T k1_0 + mid * M_1, else 0
         uint32_t valid_c;                   // KIND_ROW_N: rows of this tile that exist
     };
 
@@ -140,6 +152,7 @@ struct Pass {
     static TOYNI_HD Tile tile_of(const PassArgs& a, uint32_t bid) {
         Tile t;
         t.col0 = 0;
+        t.out0 = 0;
         t.valid_c = C;
         t.row_shift = 0;
         if (KIND == KIND_COL) {
@@ -157,6 +170,7 @@ struct Pass {
             t.row_shift = a.log_n - a.log_M1;
             t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM));
             t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
+            t.out0 = k1_0 + (mid << a.log_M1);
         } else {
             const uint64_t row0 = (uint64_t)bid << LC;
             t.in = a.in + (row0 << LM);
@@ -210,6 +224,11 @@ struct Pass {
             r.a_hi = a.tw_hi[ea >> a.tw_lowbits];
             r.g_lo = a.tw_lo[eg & mask];
             r.g_hi = a.tw_hi[eg >> a.tw_lowbits];
+        } else if (a.cs_mode == 2u) {
+            // output coset factor s^k of the group's first element (b = 0): the in-transform output index
+            const uint32_t e0 = KIND == KIND_ROW_T ? t.out0 + c + (khi << (a.log_n - LM)) : khi;
+            r.a_lo = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
+            r.a_hi = a.cs_hi[e0 >> a.cs_lowbits];
         }
         return r;
     }
@@ -219,6 +238,10 @@ struct Pass {
             tw.a0 = mont_mul(r.a_hi, r.a_lo);
             if (a.scale) tw.a0 = mont_mul(tw.a0, a.scale);
             tw.g = mont_mul(r.g_hi, r.g_lo);
+        } else if (a.cs_mode == 2u) {
+            tw.a0 = mont_mul(r.a_hi, r.a_lo);
+            if (KIND == KIND_ROW_N && a.scale) tw.a0 = mont_mul(tw.a0, a.scale);  // 1-pass inverse: n^-1 rides along
+            tw.g = a.cs_g;
         }
         return tw;
     }
@@ -237,6 +260,13 @@ struct Pass {
         const uint32_t step = (out_offset(a, 0u, 1u << LSH) - out_offset(a, 0u, 0u)) << 2;
         char* base = reinterpret_cast<char*>(t.out);
         if (KIND == KIND_COL) {
+            uint32_t tw = twd.a0;
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) {
+                st32(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
+                if (b + 1 < NB) { tw = mont_mul(tw, twd.g); TOYNI_PIN(tw); }
+            }
+        } else if (a.cs_mode == 2u) {  // inverse coset transform: * s^k, k = k0 + b * (register step), running product
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
@@ -322,6 +352,31 @@ struct Pass {
         }
     }
 
+    // (a') forward coset transform (cs_mode 1): the thread's inputs are x[j0 + i * dj]; scale them by s^(j0 + i dj) =
+    //      A * G^i -- one table lookup pair per thread and a running product (G = a.cs_g is uniform)
+    struct InSeedRaw { uint32_t lo, hi; };
+    static TOYNI_HD InSeedRaw in_seed_issue(const PassArgs& a, const Tile& t, uint32_t tid) {
+        InSeedRaw r{0u, 0u};
+        if (KIND != KIND_ROW_T && a.cs_mode == 1u) {
+            uint32_t c, lo;
+            coords1(tid, c, lo);
+            const uint32_t j0 = KIND == KIND_COL ? (lo << a.log_S) + t.col0 + c : lo;  // in-transform index of register 0
+            r.lo = a.cs_lo[j0 & ((1u << a.cs_lowbits) - 1u)];
+            r.hi = a.cs_hi[j0 >> a.cs_lowbits];
+        }
+        return r;
+    }
+    static TOYNI_HD void in_scale(const PassArgs& a, const InSeedRaw& r, uint32_t (&x)[E1]) {
+        if (KIND != KIND_ROW_T && a.cs_mode == 1u) {
+            uint32_t tw = mont_mul(r.hi, r.lo);
+#pragma unroll
+            for (uint32_t i = 0; i < E1; ++i) {
+                x[i] = mont_mul(x[i], tw);
+                if (i + 1 < E1) { tw = mont_mul(tw, a.cs_g); TOYNI_PIN(tw); }
+            }
+        }
+    }
+
     // (b) the LE1 high-bit stages in registers, then park the tile in LDS (two-step) or finish (single-step)
     static TOYNI_HD void step1(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1], uint32_t* lds, const Uniform& uni,
                                const uint32_t* tw1) {
@@ -378,6 +433,7 @@ struct Pass {
         const Tile t = tile_of(a, tile_id);
         uint32_t x[E1];
         load_tile(a, t, tid, x);
+        in_scale(a, in_seed_issue(a, t, tid), x);
         step1(a, t, tid, x, lds, load_uniform(a), tw1_global(a));
     }
     static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {

@@ -174,9 +174,19 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f) {
 // needed when npasses > 1).  `tables` points at the direction's blob wherever the executor can read it
 // (device memory for the HIP launcher, host memory for tests/emu).  launch(PassType{}, args, nblocks).
 // n = 1 launches nothing: the caller copies src to dst if they differ.
+// Coset scaling fused into the transform (BabyBearDomain, src/math/domain.rs:85-123,154-174): `s` is the factor whose
+// powers scale the data (shift for a forward coset FFT, shift^-1 for an inverse one), lo/hi its two-level power table
+// wherever the executor can read it.  lo == nullptr: plain transform.
+struct CosetTables {
+    const uint32_t* lo = nullptr;
+    const uint32_t* hi = nullptr;
+    uint32_t lowbits = 0;
+    uint32_t s = 1;  // plain canonical
+};
+
 template <class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
-                          uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch) {
+                          uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables()) {
     if (plan.log_n == 0 || batch == 0) return true;  // n = 1: identity
     const uint64_t total_log = (uint64_t)plan.log_n;
     for (int p = 0; p < plan.npasses; ++p) {
@@ -202,6 +212,20 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         }
         bool ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) {
             using P = decltype(pass);
+            // forward coset FFT scales the INPUT of the first pass by s^j, inverse scales the OUTPUT of the last by s^k
+            const bool cs_here = cs.lo && (inverse ? p == plan.npasses - 1 : p == 0);
+            if (cs_here) {
+                a.cs_lo = cs.lo;
+                a.cs_hi = cs.hi;
+                a.cs_lowbits = cs.lowbits;
+                a.cs_mode = inverse ? 2u : 1u;
+                // index distance between two consecutive registers of a thread
+                uint64_t dj;
+                if (!inverse) dj = pp.kind == KIND_COL ? ((uint64_t)P::E2 << pp.log_s) : (uint64_t)P::E2;
+                else dj = pp.kind == KIND_ROW_T ? ((uint64_t)1 << (P::TWO_STEP ? P::LE1_ : 0)) << (plan.log_n - P::LM)
+                                                : ((uint64_t)1 << (P::TWO_STEP ? P::LE1_ : 0));
+                a.cs_g = to_mont_host(bb_pow_host(cs.s, dj));
+            }
             uint64_t nblocks;
             if (pp.kind == KIND_ROW_N) nblocks = (batch + P::C - 1) / P::C;
             else nblocks = (batch << (total_log - P::LM)) / P::C;  // tiles of C columns / rows, each M long

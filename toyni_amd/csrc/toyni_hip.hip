@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
         typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
         P::template load_tile<0, NPF>(a, t, tid, x);
         typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
+        typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
         const typename P::Uniform uni = P::load_uniform(a);  // step-2 twiddles, SGPR-resident for the whole loop
         for (uint32_t j = tid; j < P::TW1_WORDS; j += P::T) lds_tw1[j] = P::tw1_global(a)[j];
         TOYNI_WAIT_VMEM0();  // the first tile's loads have landed: the loop is entered with no load pending on any path
@@ -64,6 +65,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
             if constexpr (kind_of<P>() != KIND_ROW_N) TOYNI_WAIT_VMEM_ALLOW(P::E1);
             else TOYNI_WAIT_VMEM0();
             P::template load_tile<NPF, P::E1>(a, t, tid, x);
+            P::in_scale(a, inraw, x);  // forward coset FFT only (uniform branch)
             P::step1(a, t, tid, x, lds, uni, lds_tw1);
             typename P::Seeds seeds = P::seeds_finish(a, raw);
 #pragma unroll
@@ -76,6 +78,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
                 tn = P::tile_of(a, P::tile_order(vn, ntiles));
                 P::template load_tile<0, NPF>(a, tn, tid, x);  // prefetch
                 raw = P::seeds_issue(a, tn, tid);              // and the next tile's seed lookups, still ahead of the stores
+                inraw = P::in_seed_issue(a, tn, tid);
             }
             TOYNI_SCHED_FENCE();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
@@ -100,19 +103,6 @@ __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict_
 __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = in[i];
-}
-
-// out[b*n + i] = in[b*n + i] * s^i, s^i from a two-level table of the coset shift (src/math/domain.rs:154-174)
-__global__ void __launch_bounds__(256) coset_scale_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t total,
-                                                           uint32_t log_n, const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
-                                                           uint32_t lowbits) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const uint32_t nmask = (1u << log_n) - 1u, lmask = (1u << lowbits) - 1u;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint32_t i = (uint32_t)g & nmask;
-        const uint32_t s = mont_mul(hi[i >> lowbits], lo[i & lmask]);
-        out[g] = mont_mul(in[g], s);
-    }
 }
 
 // 4-step twiddle: data[r][k] *= w_n^(+-(row0 + r) k), r < rows, k < row_len (two-level domain table of the ctx)
@@ -266,8 +256,9 @@ __global__ void __launch_bounds__(256) microbench_kernel(uint32_t seed, int iter
 // context
 // ------------------------------------------------------------------------------------------------
 struct ShiftTable {
-    uint32_t* d = nullptr;  // [fwd lo | fwd hi | inv lo | inv hi]
+    uint32_t* d = nullptr;  // two-level power tables of shift (dir 0) and shift^-1 (dir 1)
     uint32_t lo_off[2], hi_off[2], lowbits;
+    uint32_t s[2];
 };
 
 struct toyni_ntt_ctx {
@@ -348,9 +339,23 @@ unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
 }
 
 // enqueue the passes of `batch` transforms; d_in == d_out allowed
-int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s) {
+int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
+
+// shift != 1: the coset scaling of BabyBearDomain::fft / ifft is fused into the first / last pass
+int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u) {
     if (batch == 0) return 0;
     const size_t n = c->n;
+    CosetTables cs;
+    if (shift != 1u && c->plan.log_n > 0) {
+        ShiftTable* st = nullptr;
+        int rc = get_shift_table(c, shift, &st);
+        if (rc) return rc;
+        const int dir = inverse ? 1 : 0;
+        cs.lo = st->d + st->lo_off[dir];
+        cs.hi = st->d + st->hi_off[dir];
+        cs.lowbits = st->lowbits;
+        cs.s = st->s[dir];
+    }
     if (c->plan.log_n == 0) {
         if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         return 0;
@@ -375,7 +380,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                     if (err != hipSuccess) return;
                                     launch_pass<P>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
                                     err = hipGetLastError();
-                                });
+                                }, cs);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
     }
@@ -387,35 +392,14 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out) {
     if (it != c->shifts.end()) { *out = &it->second; return 0; }
     ShiftTable st;
     std::vector<uint32_t> blob;
-    const uint32_t sinv = bb_inv_host(shift);  // src/math/domain.rs:167
-    for (int dir = 0; dir < 2; ++dir) {
-        // generic two-level powers of (shift or shift^-1): index i < n
-        const uint32_t base = dir ? sinv : shift;
-        st.lowbits = (uint32_t)((c->plan.log_n + 1) / 2);
-        st.lo_off[dir] = (uint32_t)blob.size();
-        uint32_t cur = 1;
-        for (uint32_t x = 0; x < (1u << st.lowbits); ++x) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, base); }
-        st.hi_off[dir] = (uint32_t)blob.size();
-        const uint32_t step = cur;
-        cur = 1;
-        for (uint32_t y = 0; y < (1u << (c->plan.log_n - st.lowbits)); ++y) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, step); }
-    }
+    st.s[0] = shift;
+    st.s[1] = bb_inv_host(shift);  // src/math/domain.rs:167
+    for (int dir = 0; dir < 2; ++dir) append_two_level(blob, c->plan.log_n, st.s[dir], 1u, st.lo_off[dir], st.hi_off[dir], st.lowbits);
     HIPCHK(hipMalloc((void**)&st.d, blob.size() * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(st.d, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     auto ins = c->shifts.emplace(shift, st);
     *out = &ins.first->second;
     return 0;
-}
-
-int enqueue_coset_scale(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, bool inverse, hipStream_t s) {
-    ShiftTable* st = nullptr;
-    int rc = get_shift_table(c, shift, &st);
-    if (rc) return rc;
-    const size_t total = batch * (size_t)c->n;
-    const int dir = inverse ? 1 : 0;
-    hipLaunchKernelGGL(coset_scale_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, d_out, total, (uint32_t)c->plan.log_n,
-                       st->d + st->lo_off[dir], st->d + st->hi_off[dir], st->lowbits);
-    return (int)hipGetLastError();
 }
 
 bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
@@ -520,15 +504,9 @@ int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_o
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
-    if (shift == 1) return enqueue_transform(c, d_in, d_out, batch, inverse != 0, s);  // src/math/domain.rs:155,166
-    int rc;
-    if (!inverse) {  // scale by shift^i, then NTT (src/math/domain.rs:111,121)
-        if ((rc = enqueue_coset_scale(c, d_in, d_out, batch, shift, false, s))) return rc;
-        return enqueue_transform(c, d_out, d_out, batch, false, s);
-    }
-    // INTT, then scale by shift^-i (src/math/domain.rs:99-100)
-    if ((rc = enqueue_transform(c, d_in, d_out, batch, true, s))) return rc;
-    return enqueue_coset_scale(c, d_out, d_out, batch, shift, true, s);
+    // forward: scale by shift^i then NTT (src/math/domain.rs:111,121); inverse: INTT then scale by shift^-i (:99-100);
+    // shift == 1 is the plain transform (:155,166).  The scaling is fused into the first / last pass.
+    return enqueue_transform(c, d_in, d_out, batch, inverse != 0, s, shift);
 }
 
 int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int inverse, void* stream) {
@@ -559,9 +537,7 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
     if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));  // cuda/ntt_kernel.cu:254
     hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_stage64, c->d_data32, total);
-    if (shift != 1 && !inverse) { if ((rc = enqueue_coset_scale(c, c->d_data32, c->d_data32, batch, shift, false, s))) return rc; }
-    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s))) return rc;
-    if (shift != 1 && inverse) { if ((rc = enqueue_coset_scale(c, c->d_data32, c->d_data32, batch, shift, true, s))) return rc; }
+    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s, shift))) return rc;
     hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_data32, c->d_stage64, total);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_data, c->d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));  // cuda/ntt_kernel.cu:267
