@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--microbench", action="store_true", help="also print integer-multiply issue rates (stderr)")
+    ap.add_argument("--workload", choices=["batch", "fourstep"], default="batch",
+                    help="batch: the default sharded batch (weak scaling); fourstep: ONE transform of n = 2^log-n split over "
+                         "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit)")
     return ap.parse_args()
 
 
@@ -64,6 +67,50 @@ def cpu_baseline(log_n, seconds):
     }
 
 
+def bench_fourstep(args, dev, rank, world, distributed):
+    """One size-n transform over all ranks: local column transforms + twiddle, ONE all-to-all (RCCL), local row transforms."""
+    import torch
+    import torch.distributed as dist
+    from toyni_amd import dist as tdist
+    log_n = args.log_n
+    l1, l2 = tdist.fourstep_split(log_n, world)
+    ops = tdist.HipLocalOps(log_n, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x4057E9 + rank)
+    cols = torch.randint(0, P, ((1 << l1), (1 << l2) // world), dtype=torch.int32, device=dev, generator=gen)
+
+    def step():
+        out = tdist.fourstep_forward(cols, log_n, ops, rank, world)
+        return tdist.fourstep_inverse(out, log_n, ops, rank, world)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        back = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        back = step()
+    fence()
+    wall = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.equal(back, cols), "4-step round trip changed the data"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "BabyBear NTT throughput, single transform split over GPUs (4-step, one all-to-all)", "value": 2 * args.steps * (1 << log_n) / wall,
+            "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"forward+inverse 4-step NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
+                       "log_n": log_n, "parallelism": f"column/row split x{world}, RCCL all-to-all"},
+            "roofline": None, "cpu_baseline": None,
+        }))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import numpy as np
@@ -87,6 +134,9 @@ def main():
     if distributed:
         dist.barrier()
     import toyni_amd
+
+    if args.workload == "fourstep":
+        return bench_fourstep(args, dev, rank, world, distributed)
 
     n = 1 << args.log_n
     batch = args.batch
@@ -231,6 +281,31 @@ def main():
             th = (time.perf_counter() - t0h) / reps_h
             extras[f"host_slice_n2^{ln}"] = {"ms": th * 1e3, "elements_per_s": nn / th, "note": "ntt_cuda-shaped call: H2D u64 + kernels + D2H u64, pageable host memory"}
             c1.destroy()
+        # ---- prover-shaped sequence (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident: the NTT /
+        #      fold work of one proof: interpolate (INTT 2^16), coset LDE (zero-pad + coset FFT 2^21), the two coset INTTs of
+        #      src/fibonacci.rs:145,151, and the 17 FRI folds 2^21 -> 2^4 (src/fibonacci.rs:220-245).  Merkle/transcript and
+        #      the pointwise constraint evaluation are outside this path.
+        lt, ll = 16, 21
+        c_t, c_l = toyni_amd.NttContext(1 << lt, device=dev.index), toyni_amd.NttContext(1 << ll, device=dev.index)
+        trace = torch.randint(0, P, (1 << lt,), dtype=torch.int32, device=dev)
+        lde = torch.zeros(1 << ll, dtype=torch.int32, device=dev)
+        q1 = torch.randint(0, P, (1 << ll,), dtype=torch.int32, device=dev)
+        q2 = torch.randint(0, P, (1 << ll,), dtype=torch.int32, device=dev)
+        layers = torch.empty(1 << ll, dtype=torch.int32, device=dev)
+        betas = np.random.default_rng(5).integers(0, P, 17, dtype=np.uint32)
+
+        def prove_shape():
+            c_t.run_device(trace.data_ptr(), lde.data_ptr(), 1, True, stream=stream)          # coefficients into lde[0 : 2^16]
+            lde[(1 << lt):].zero_()
+            c_l.run_device(lde.data_ptr(), lde.data_ptr(), 1, False, stream=stream, shift=7)   # coset LDE
+            c_l.run_device(q1.data_ptr(), q1.data_ptr(), 1, True, stream=stream, shift=7)      # ifft #1
+            c_l.run_device(q2.data_ptr(), q2.data_ptr(), 1, True, stream=stream, shift=7)      # ifft #2
+            toyni_amd.fri_fold_layers_device(c_l, lde.data_ptr(), layers.data_ptr(), betas, 7, stream=stream)
+
+        t_p = time_dev(prove_shape, 20)
+        extras["prover_shape_trace2^16_lde2^21"] = {
+            "us": t_p * 1e6, "note": "INTT 2^16 + coset FFT 2^21 + 2 coset INTT 2^21 + 17 folds, device-resident, 22 launches",
+        }
         out["extras"] = extras
 
     if rank == 0 and args.microbench:
