@@ -35,12 +35,6 @@ struct NttPlan {
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
 
-// step split of a pass: LE1 high bits in step 1, LE2 low bits in step 2
-inline void split_steps(int log_m, int& le1, int& le2) {
-    if (log_m <= 5) { le1 = log_m; le2 = 0; }
-    else { le1 = (log_m + 1) / 2; le2 = log_m / 2; }
-}
-
 inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES]) {
     if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
     if (log_n <= 20) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
