@@ -86,6 +86,13 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* ctx, uint64_t* d_data, size_t batch, int
 int toyni_coset_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream);
 int toyni_coset_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, uint64_t shift, int inverse);
 
+/* Extension-field transforms, fft_ext / ifft_ext (src/math/domain.rs:129-151): n Ext elements = 4 words each (AoS,
+ * #[repr(C)] Ext { c: [BabyBear; 4] }).  The transform is base-linear, so it is the four coordinate transforms -- issued
+ * here as ONE batch of 4 behind ONE call (host form: one PCIe round trip; the de-interleave runs on the device).
+ * shift = coset shift (1 = standard domain). */
+int toyni_ntt_ext_host(toyni_ntt_ctx* ctx, uint64_t* h_data, uint64_t shift, int inverse);
+int toyni_ntt_ext_device(toyni_ntt_ctx* ctx, uint32_t* d_data, uint32_t shift, int inverse, void* stream);
+
 /* Multi-GPU 4-step transform of one size-n vector (n = n1 * n2 over G ranks, one all-to-all): the twiddle between
  * the two local stages, d_data[r][k] *= w_n^(+-(row0 + r) * k) for r < rows, k < row_len (ctx of size n;
  * (row0 + rows) * row_len <= n).  The local stages are toyni_ntt_device batches; the exchange is the caller's

@@ -517,3 +517,24 @@ def test_fold_ext_embeds_base_fold(ta):
     assert (out[:, 0] == oracle.fri_fold(evals, xs, 424242)).all() and not out[:, 1:].any()
     with pytest.raises(AssertionError, match="even"):
         ta.fri_fold_ext(np.zeros((3, 4), dtype=np.uint64), np.ones(3, dtype=np.uint64), [1, 0, 0, 0])
+
+
+@pytest.mark.parametrize("log_n,shift", [(3, 1), (10, 7), (16, 7)])
+def test_ext_transform_single_call(ta, log_n, shift):
+    # fft_ext / ifft_ext (src/math/domain.rs:129-151) as one device call: equals four base transforms of the coordinates
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    vals = rng.integers(0, P, size=(n, 4)).astype(np.uint64)
+    d = ta.BabyBearDomain(n).with_gpu(True).get_coset(shift)
+    evals = d.fft_ext(vals)
+    for k in range(4):
+        assert (evals[:, k] == oracle.domain_fft(vals[:, k], n, shift)).all()
+    assert (d.ifft_ext(evals) == vals).all()
+    # device-resident AoS form
+    ctx = ta.ntt.get_or_create_ctx(n)
+    buf = DevBuf(ta, n * 16)
+    buf.upload(vals.astype(np.uint32))
+    ctx.run_device_ext(buf.ptr, False, shift=shift)
+    ctx.synchronize()
+    assert (buf.download(np.uint32, 4 * n).reshape(n, 4) == evals).all()
+    buf.free()

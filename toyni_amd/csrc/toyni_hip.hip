@@ -105,6 +105,25 @@ __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = in[i];
 }
 
+// Ext (4 coordinates per element, AoS) <-> four base-field columns (SoA): the de-interleave / recombine of
+// BabyBearDomain::transform_ext (src/math/domain.rs:140-151), on the device.  IN = uint64_t (host layout, reduced) or uint32_t.
+template <class IN>
+__global__ void __launch_bounds__(256) ext_split_kernel(const IN* __restrict__ aos, uint32_t* __restrict__ soa, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) soa[(size_t)k * n + i] = (uint32_t)(aos[4 * i + k] % BB_P);
+    }
+}
+template <class OUT>
+__global__ void __launch_bounds__(256) ext_join_kernel(const uint32_t* __restrict__ soa, OUT* __restrict__ aos, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) aos[4 * i + k] = soa[(size_t)k * n + i];
+    }
+}
+
 // 4-step twiddle: data[r][k] *= w_n^(+-(row0 + r) k), r < rows, k < row_len (two-level domain table of the ctx)
 __global__ void __launch_bounds__(256) fourstep_twiddle_kernel(uint32_t* __restrict__ data, uint64_t total, uint32_t log_len, uint32_t row0,
                                                                 const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t lowbits) {
@@ -546,6 +565,44 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
 }
 
 int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse) { return host_transform(c, h_data, batch, 1u, inverse); }
+
+// fft_ext / ifft_ext (src/math/domain.rs:129-151): one call, one PCIe round trip, the four coordinate transforms as ONE batch of 4
+int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int inverse) {
+    if (!c || !h_data) return TOYNI_E_NULL;
+    shift %= BB_P;
+    if (shift == 0) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const size_t n = c->n, total = 4 * n;
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, total, sizeof(uint64_t)))) return rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_stage64, c->d_data32, n);
+    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, (uint32_t)shift))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_data, c->d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return TOYNI_OK;
+}
+
+// device-resident Ext transform on AoS packed u32 (n elements x 4 coordinates), in place
+int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int inverse, void* stream) {
+    if (!c || !d_data) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const size_t n = c->n;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, c->d_data32, n);
+    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, shift))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, d_data, n);
+    return (int)hipGetLastError();
+}
 
 int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint64_t shift, int inverse) {
     if (shift >= BB_P) shift %= BB_P;

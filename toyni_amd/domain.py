@@ -61,7 +61,8 @@ class BabyBearDomain:
         self._require_gpu()
         v = np.asarray(vals4, dtype=np.uint64).reshape(-1, 4)
         assert v.shape[0] <= self.size if not inverse else v.shape[0] == self.size
-        coords = np.zeros((4, self.size), dtype=np.uint64)  # de-interleave: src/math/domain.rs:141-147
-        coords[:, : v.shape[0]] = v.T
-        _ntt.get_or_create_ctx(self.size).run_host(coords.reshape(-1), inverse=inverse, batch=4, shift=self.shift)
-        return np.ascontiguousarray(coords.T)
+        vals = np.zeros((self.size, 4), dtype=np.uint64)  # zero-pad like fft (src/math/domain.rs:109)
+        vals[: v.shape[0]] = v
+        # the de-interleave / four transforms / recombine of src/math/domain.rs:140-151 happen on the device in one call
+        _ntt.get_or_create_ctx(self.size).run_host_ext(vals.reshape(-1), inverse=inverse, shift=self.shift)
+        return vals

@@ -103,6 +103,15 @@ class NttContext:
         else:
             check(lib.toyni_coset_ntt_device(self.handle, d_in, d_out, batch, shift, int(inverse), stream or None), "GPU coset NTT failed")
 
+    def run_host_ext(self, values4: np.ndarray, inverse: bool, shift: int = 1) -> None:
+        """n Ext elements ([n, 4] u64, AoS) in place: the four coordinate transforms as one batch, one PCIe round trip."""
+        v = _as_u64(values4)
+        assert v.size == 4 * self.n, "Size mismatch"
+        check(lib.toyni_ntt_ext_host(self.handle, v.ctypes.data, shift, int(inverse)), "GPU Ext NTT failed")
+
+    def run_device_ext(self, d_data: int, inverse: bool, shift: int = 1, stream: int = 0) -> None:
+        check(lib.toyni_ntt_ext_device(self.handle, d_data, shift, int(inverse), stream or None), "GPU Ext NTT failed")
+
     def run_device_u64(self, d_data: int, batch: int, inverse: bool, stream: int = 0) -> None:
         check(lib.toyni_ntt_device_u64(self.handle, d_data, batch, int(inverse), stream or None), "GPU NTT failed")
 
