@@ -125,6 +125,17 @@ int toyni_fri_fold_ext_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, 
 int toyni_fri_fold_ext_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, const uint64_t beta[4]);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3b. Merkle commitment of a layer (oracle: src/merkle.rs:25-48,105-123 and the leaf format of
+ *     build_merkle_tree / build_unsalted_tree, src/fibonacci.rs:340-361).  leaf = SHA256(0x00 || salt[16] || value as 8 LE
+ *     bytes) -- or 0x00 || value bytes when salts == NULL; node = SHA256(0x01 || left || right); odd levels duplicate
+ *     their last node.  Output: ALL levels back to back as 32-byte digests (leaf hashes first, root last) =
+ *     MerkleTree::levels; toyni_merkle_total_digests(n) digests.  d_levels / d_salts 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+size_t toyni_merkle_total_digests(size_t n);
+int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts, size_t n, uint8_t* d_levels, void* stream);
+int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, size_t n, uint8_t* h_levels);
+
+/* ------------------------------------------------------------------------------------------------
  * 4. Plumbing
  * ---------------------------------------------------------------------------------------------- */
 int toyni_malloc(void** d_ptr, size_t bytes);

@@ -57,6 +57,12 @@ for _name, _res, _args in [
     ("orc_fri_fold", ctypes.c_int, [_p64, _p64, _sz, _p64, _u64]),
     ("orc_fri_fold_layers", ctypes.c_int, [_p64, _p64, _sz, _u64, _p64, ctypes.c_uint]),
     ("orc_fri_fold_ext", ctypes.c_int, [_p64, _p64, _sz, _p64, _p64]),
+    ("orc_sha256", None, [ctypes.c_void_p, ctypes.c_void_p, _sz]),
+    ("orc_hash_leaf", None, [ctypes.c_void_p, ctypes.c_void_p, _sz]),
+    ("orc_hash_node", None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("orc_merkle_total_digests", _sz, [_sz]),
+    ("orc_merkle_levels", None, [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
+    ("orc_merkle_commit_values", None, [ctypes.c_void_p, _p64, ctypes.c_void_p, _sz]),
     ("orc_fill_pattern_7i3", None, [_p64, _sz]),
     ("orc_fill_splitmix", None, [_p64, _sz, _u64]),
 ]:
@@ -182,3 +188,64 @@ def splitmix(n, seed=0x70796E69) -> np.ndarray:
     out = np.empty(n, dtype=np.uint64)
     _lib.orc_fill_splitmix(_ptr(out), n, seed)
     return out
+
+
+# ---- Merkle commitment (src/merkle.rs, src/fibonacci.rs:340-361) ----
+def sha256(msg: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    _lib.orc_sha256(out, msg, len(msg))
+    return out.raw
+
+
+def hash_leaf(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    _lib.orc_hash_leaf(out, data, len(data))
+    return out.raw
+
+
+def hash_node(left: bytes, right: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    _lib.orc_hash_node(out, left, right)
+    return out.raw
+
+
+def merkle_level_sizes(n: int):
+    sizes = []
+    while n >= 1:
+        sizes.append(n)
+        if n == 1:
+            break
+        n = (n + 1) // 2
+    return sizes
+
+
+def _split_levels(flat: np.ndarray, n: int):
+    out, off = [], 0
+    for m in merkle_level_sizes(n):
+        out.append(flat[off:off + m])
+        off += m
+    return out
+
+
+def merkle_levels(leaves) -> list:
+    """MerkleTree::new(leaves).levels for equal-length byte-string leaves: list of [count, 32] uint8 arrays."""
+    n = len(leaves)
+    ln = len(leaves[0])
+    assert all(len(l) == ln for l in leaves)
+    flat = np.zeros((int(_lib.orc_merkle_total_digests(n)), 32), dtype=np.uint8)
+    buf = b"".join(leaves)
+    _lib.orc_merkle_levels(flat.ctypes.data, buf, ln, n)
+    return _split_levels(flat, n)
+
+
+def merkle_commit_values(values, salts=None) -> list:
+    """build_merkle_tree / build_unsalted_tree: levels of the tree over leaf = salt(16) || value(8, LE) or value alone."""
+    v = _arr(values)
+    n = v.size
+    flat = np.zeros((int(_lib.orc_merkle_total_digests(n)), 32), dtype=np.uint8)
+    sp = None
+    if salts is not None:
+        s = np.ascontiguousarray(salts, dtype=np.uint8).reshape(n, 16)
+        sp = s.ctypes.data
+    _lib.orc_merkle_commit_values(flat.ctypes.data, _ptr(v), sp, n)
+    return _split_levels(flat, n)

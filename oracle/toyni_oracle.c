@@ -310,3 +310,115 @@ static uint64_t orc_splitmix64(uint64_t x) {
 void orc_fill_splitmix(uint64_t *out, size_t n, uint64_t seed) {
     for (size_t i = 0; i < n; ++i) out[i] = orc_splitmix64(seed + (uint64_t)i) % BB_P;
 }
+
+/* ================================================================================================
+ * Merkle commitment of a layer of field elements (SURVEY.md 8(f) rank 2 -- "next" row).
+ * SHA-256 is FIPS 180-4 (the reference takes it from the `sha2 0.10.8` crate, Cargo.toml:13; not vendored
+ * in /root/reference, so the published algorithm is restated here and pinned against Python's hashlib in
+ * tests/test_oracle.py).  Tree shape, tags and leaf format follow the reference's own code.
+ * ============================================================================================== */
+static const uint32_t ORC_K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static uint32_t orc_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+static void orc_sha256_block(uint32_t st[8], const uint8_t blk[64]) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+        uint32_t s0 = orc_rotr(w[i - 15], 7) ^ orc_rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = orc_rotr(w[i - 2], 17) ^ orc_rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; ++i) {
+        uint32_t t1 = h + (orc_rotr(e, 6) ^ orc_rotr(e, 11) ^ orc_rotr(e, 25)) + ((e & f) ^ (~e & g)) + ORC_K256[i] + w[i];
+        uint32_t t2 = (orc_rotr(a, 2) ^ orc_rotr(a, 13) ^ orc_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+void orc_sha256(uint8_t out[32], const uint8_t *msg, size_t len) {
+    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t off = 0;
+    for (; off + 64 <= len; off += 64) orc_sha256_block(st, msg + off);
+    uint8_t tail[128];
+    size_t rem = len - off;
+    memset(tail, 0, sizeof tail);
+    memcpy(tail, msg + off, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; ++i) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    orc_sha256_block(st, tail);
+    if (tl == 128) orc_sha256_block(st, tail + 64);
+    for (int i = 0; i < 8; ++i) { out[4 * i] = st[i] >> 24; out[4 * i + 1] = st[i] >> 16; out[4 * i + 2] = st[i] >> 8; out[4 * i + 3] = st[i]; }
+}
+
+/* src/merkle.rs:105-114 hash_leaf: SHA256(0x00 || leaf) */
+void orc_hash_leaf(uint8_t out[32], const uint8_t *data, size_t len) {
+    uint8_t *buf = (uint8_t *)malloc(len + 1);
+    buf[0] = 0x00;
+    memcpy(buf + 1, data, len);
+    orc_sha256(out, buf, len + 1);
+    free(buf);
+}
+
+/* src/merkle.rs:116-123 hash_node: SHA256(0x01 || left || right) */
+void orc_hash_node(uint8_t out[32], const uint8_t left[32], const uint8_t right[32]) {
+    uint8_t buf[65];
+    buf[0] = 0x01;
+    memcpy(buf + 1, left, 32);
+    memcpy(buf + 33, right, 32);
+    orc_sha256(out, buf, 65);
+}
+
+/* number of digests in all levels of a tree over n leaves (src/merkle.rs:25-48: halve, rounding up, until 1) */
+size_t orc_merkle_total_digests(size_t n) {
+    size_t total = 0;
+    if (n == 0) return 0;
+    for (;;) { total += n; if (n == 1) break; n = (n + 1) / 2; }
+    return total;
+}
+
+/* src/merkle.rs:25-48 build_tree over already-hashed leaves stored at levels[0 .. n); appends every upper level.
+ * An odd level duplicates its last node (:38-42). */
+static void orc_merkle_build_upper(uint8_t *levels, size_t n) {
+    uint8_t *cur = levels;
+    while (n > 1) {
+        uint8_t *next = cur + 32 * n;
+        size_t m = (n + 1) / 2;
+        for (size_t i = 0; i < m; ++i) {
+            const uint8_t *l = cur + 32 * (2 * i);
+            const uint8_t *r = (2 * i + 1 < n) ? cur + 32 * (2 * i + 1) : l;
+            orc_hash_node(next + 32 * i, l, r);
+        }
+        cur = next;
+        n = m;
+    }
+}
+
+/* MerkleTree::new(leaves) for byte-string leaves of a common length: all levels back to back, leaf hashes first */
+void orc_merkle_levels(uint8_t *levels, const uint8_t *leaves, size_t leaf_len, size_t n) {
+    for (size_t i = 0; i < n; ++i) orc_hash_leaf(levels + 32 * i, leaves + leaf_len * i, leaf_len);
+    orc_merkle_build_upper(levels, n);
+}
+
+/* build_merkle_tree / build_unsalted_tree (src/fibonacci.rs:340-361): leaf = salt[16] || value.to_bytes() (8-byte LE,
+ * src/babybear.rs:53-55), or just the 8 value bytes when salts == NULL. */
+void orc_merkle_commit_values(uint8_t *levels, const uint64_t *values, const uint8_t *salts, size_t n) {
+    uint8_t leaf[24];
+    for (size_t i = 0; i < n; ++i) {
+        size_t len = 0;
+        if (salts) { memcpy(leaf, salts + 16 * i, 16); len = 16; }
+        for (int b = 0; b < 8; ++b) leaf[len + b] = (uint8_t)(values[i] >> (8 * b));
+        orc_hash_leaf(levels + 32 * i, leaf, len + 8);
+    }
+    orc_merkle_build_upper(levels, n);
+}

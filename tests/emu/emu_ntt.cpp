@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ntt_plan.hpp"
+#include "merkle_kernels.hpp"
 
 extern "C" {
 uint64_t orc_bb_mul(uint64_t, uint64_t);
@@ -27,6 +28,8 @@ int orc_fri_fold(uint64_t*, const uint64_t*, size_t, const uint64_t*, uint64_t);
 int orc_domain_elements(uint64_t*, size_t, uint64_t);
 int orc_fri_fold_ext(uint64_t*, const uint64_t*, size_t, const uint64_t*, const uint64_t*);
 int orc_domain_fft(uint64_t*, size_t, const uint64_t*, size_t, uint64_t);
+void orc_merkle_commit_values(uint8_t*, const uint64_t*, const uint8_t*, size_t);
+size_t orc_merkle_total_digests(size_t);
 int orc_domain_ifft(uint64_t*, size_t, uint64_t);
 }
 
@@ -196,6 +199,31 @@ static void test_fold_ext(size_t len) {
     CHECK(bad == 0, "fold_ext len=%zu: %zu mismatches", len, bad);
 }
 
+// Merkle: leaf / node digests of merkle_kernels.hpp vs the oracle's byte-level tree (src/merkle.rs:25-48,105-123)
+static void test_merkle(size_t n, bool salted) {
+    std::vector<uint64_t> vals(n);
+    orc_fill_splitmix(vals.data(), n, 0x3E2C1Eull + n);
+    std::vector<uint8_t> salts(16 * n);
+    for (size_t i = 0; i < salts.size(); ++i) salts[i] = (uint8_t)(i * 131 + 7);
+    const size_t total = orc_merkle_total_digests(n);
+    std::vector<uint8_t> want(32 * total);
+    orc_merkle_commit_values(want.data(), vals.data(), salted ? salts.data() : nullptr, n);
+    std::vector<Digest> lv(total);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t sw[4];
+        std::memcpy(sw, salts.data() + 16 * i, 16);
+        lv[i] = merkle_leaf((uint32_t)vals[i], salted ? sw : nullptr);
+    }
+    size_t off = 0, m = n;
+    while (m > 1) {
+        const size_t up = (m + 1) / 2;
+        for (size_t i = 0; i < up; ++i) lv[off + m + i] = merkle_node(lv[off + 2 * i], lv[off + (2 * i + 1 < m ? 2 * i + 1 : 2 * i)]);
+        off += m;
+        m = up;
+    }
+    CHECK(std::memcmp(lv.data(), want.data(), 32 * total) == 0, "merkle n=%zu salted=%d", n, (int)salted);
+}
+
 int main(int argc, char** argv) {
     int max_log = argc > 1 ? std::atoi(argv[1]) : 16;
     test_field();
@@ -221,6 +249,7 @@ int main(int argc, char** argv) {
     test_fold(13, 12, 7);
     test_fold(1, 0, 7);
     test_fold(6, 2, 1);
+    for (size_t n : {1, 2, 3, 4, 5, 8, 100, 1024}) { test_merkle(n, false); test_merkle(n, true); }
     test_fold_ext(2);
     test_fold_ext(64);
     test_fold_ext(1024);

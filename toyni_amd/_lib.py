@@ -81,6 +81,9 @@ SIGNATURES = {
     "toyni_fri_fold_ext_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_u32, c_void_p]),
     "toyni_fri_fold_ext_xs_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
     "toyni_fri_fold_ext_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
+    "toyni_merkle_total_digests": (c_size, [c_size]),
+    "toyni_merkle_commit_device": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
+    "toyni_merkle_commit_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     # section 4
     "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
     "toyni_free": (c_int, [c_void_p]),

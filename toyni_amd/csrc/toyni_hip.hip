@@ -12,6 +12,7 @@
 
 #include "../../include/toyni_hip.h"
 #include "ntt_plan.hpp"
+#include "merkle_kernels.hpp"
 
 using namespace toyni;
 
@@ -241,6 +242,31 @@ __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __res
                 out[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
             }
         }
+    }
+}
+
+// Merkle commitment (merkle_kernels.hpp): one thread per leaf, then one thread per node, level by level
+__global__ void __launch_bounds__(256) merkle_leaf_kernel(const uint32_t* __restrict__ values, const uint4* __restrict__ salts,
+                                                           Digest* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Digest d;
+        if (salts) {
+            const uint4 s = salts[i];
+            const uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+            d = merkle_leaf(values[i], sw);
+        } else {
+            d = merkle_leaf(values[i], nullptr);
+        }
+        out[i] = d;
+    }
+}
+__global__ void __launch_bounds__(256) merkle_level_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, size_t m, size_t up) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < up; i += stride) {
+        const Digest l = cur[2 * i];
+        const Digest r = (2 * i + 1 < m) ? cur[2 * i + 1] : l;  // odd level: duplicate the last node (src/merkle.rs:38-42)
+        next[i] = merkle_node(l, r);
     }
 }
 
@@ -788,6 +814,58 @@ int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, co
 #undef FOLD_TRY
     cleanup();
     for (size_t i = 0; i < half; ++i) h_out[i] = x32[i];
+    return TOYNI_OK;
+}
+
+// ---- Merkle commitment ----
+size_t toyni_merkle_total_digests(size_t n) {
+    size_t total = 0;
+    if (n == 0) return 0;
+    for (;;) { total += n; if (n == 1) break; n = (n + 1) / 2; }
+    return total;
+}
+
+int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts, size_t n, uint8_t* d_levels, void* stream) {
+    if (!d_values || !d_levels) return TOYNI_E_NULL;
+    if (n == 0) return TOYNI_OK;
+    if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15)) return TOYNI_E_RANGE;  // 16-byte accesses
+    hipStream_t s = (hipStream_t)stream;
+    Digest* cur = reinterpret_cast<Digest*>(d_levels);
+    hipLaunchKernelGGL(merkle_leaf_kernel, dim3(grid_for(n)), dim3(256), 0, s, d_values, reinterpret_cast<const uint4*>(d_salts), cur, n);
+    size_t m = n;
+    while (m > 1) {
+        const size_t up = (m + 1) / 2;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid_for(up)), dim3(256), 0, s, (const Digest*)cur, cur + m, m, up);
+        cur += m;
+        m = up;
+    }
+    return (int)hipGetLastError();
+}
+
+int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, size_t n, uint8_t* h_levels) {
+    if (!h_values || !h_levels) return TOYNI_E_NULL;
+    if (n == 0) return TOYNI_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    std::vector<uint32_t> v32(n);
+    for (size_t i = 0; i < n; ++i) v32[i] = (uint32_t)(h_values[i] % BB_P);
+    const size_t total = toyni_merkle_total_digests(n);
+    uint32_t* d_v = nullptr;
+    uint8_t *d_s = nullptr, *d_l = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_v); (void)hipFree(d_s); (void)hipFree(d_l); };
+#define MK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
+    MK_TRY(hipMalloc((void**)&d_v, n * sizeof(uint32_t)));
+    MK_TRY(hipMalloc((void**)&d_l, total * 32));
+    MK_TRY(hipMemcpy(d_v, v32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (h_salts) {
+        MK_TRY(hipMalloc((void**)&d_s, n * 16));
+        MK_TRY(hipMemcpy(d_s, h_salts, n * 16, hipMemcpyHostToDevice));
+    }
+    int rc = toyni_merkle_commit_device(d_v, d_s, n, d_l, nullptr);
+    if (rc) { cleanup(); return rc; }
+    MK_TRY(hipMemcpy(h_levels, d_l, total * 32, hipMemcpyDeviceToHost));
+#undef MK_TRY
+    cleanup();
     return TOYNI_OK;
 }
 
