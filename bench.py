@@ -306,6 +306,13 @@ def main():
         extras["prover_shape_trace2^16_lde2^21"] = {
             "us": t_p * 1e6, "note": "INTT 2^16 + coset FFT 2^21 + 2 coset INTT 2^21 + 17 folds, device-resident, 22 launches",
         }
+        # Merkle commitment of one lde-size layer (the prover builds 3 of these plus 17 shrinking FRI layers): SURVEY 8(f) rank 2
+        from toyni_amd._lib import lib as _tlib
+        nl = 1 << ll
+        salts = torch.randint(0, 2**31 - 1, (nl * 4,), dtype=torch.int32, device=dev)
+        lv = torch.empty(_tlib.toyni_merkle_total_digests(nl) * 8, dtype=torch.int32, device=dev)
+        t_m = time_dev(lambda: toyni_amd.merkle_commit_device(q1.data_ptr(), salts.data_ptr(), nl, lv.data_ptr(), stream=stream), 20)
+        extras["merkle_commit_2^21_salted"] = {"us": t_m * 1e6, "note": "SHA-256 leaves + 21 node levels, device-resident, 22 launches"}
         out["extras"] = extras
 
     if rank == 0 and args.microbench:
