@@ -13,3 +13,12 @@ def test_kernel_bodies_match_oracle_on_cpu():
     res = subprocess.run([exe, "14", "20", "20x4", "20x16", "21"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout
+
+
+def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
+    # every tile / LDS / table index of every pass shape stays in bounds (global buffers are exactly n * batch words,
+    # the LDS array exactly LDS_WORDS + 1): 2^0..2^11 with ragged batches, 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
+    exe = entry.build_emu_sanitized()
+    res = subprocess.run([exe, "11", "20", "21"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "ALL OK" in res.stdout
