@@ -52,7 +52,7 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
     bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
-        std::vector<uint32_t> lds(P::LDS_WORDS + 1, 0xDEADBEEFu);
+        std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);  // exact size: an out-of-range LDS word is an ASan error
         for (uint64_t v = 0; v < nblocks; ++v) {
             const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);  // the persistent loop's virtual index -> tile
             for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, b, tid, lds.data());
