@@ -306,6 +306,30 @@ def main():
         extras["prover_shape_trace2^16_lde2^21"] = {
             "us": t_p * 1e6, "note": "INTT 2^16 + coset FFT 2^21 + 2 coset INTT 2^21 + 17 folds, device-resident, 22 launches",
         }
+        # the same sequence captured once into a hipGraph (the launch path allocates nothing after warm-up) and replayed
+        try:
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                gstream = side.cuda_stream
+
+                def prove_shape_on(st):
+                    c_t.run_device(trace.data_ptr(), lde.data_ptr(), 1, True, stream=st)
+                    c_l.run_device(lde.data_ptr(), lde.data_ptr(), 1, False, stream=st, shift=7)
+                    c_l.run_device(q1.data_ptr(), q1.data_ptr(), 1, True, stream=st, shift=7)
+                    c_l.run_device(q2.data_ptr(), q2.data_ptr(), 1, True, stream=st, shift=7)
+                    toyni_amd.fri_fold_layers_device(c_l, lde.data_ptr(), layers.data_ptr(), betas, 7, stream=st)
+
+                prove_shape_on(gstream)
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    prove_shape_on(torch.cuda.current_stream().cuda_stream)
+            t_g = time_dev(graph.replay, 20)
+            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_replay_us"] = t_g * 1e6
+        except Exception as exc:  # capture support is a property of the runtime, not of the kernels
+            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_replay_us"] = None
+            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_error"] = str(exc)[:200]
+
         # Merkle commitment of one lde-size layer (the prover builds 3 of these plus 17 shrinking FRI layers): SURVEY 8(f) rank 2
         from toyni_amd._lib import lib as _tlib
         nl = 1 << ll
