@@ -20,8 +20,13 @@ src = f"gpurun_out/profiles_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]  # gpurun_out accumulates runs: keep the latest only
+
+
 def counters(sub):
-    files = glob.glob(f"{src}/{sub}/*/*counter_collection.csv")
+    files = newest(f"{src}/{sub}/*/*counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -29,7 +34,7 @@ def counters(sub):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": len(next(iter(cs.values())))} for k, cs in agg.items()}
 
 
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")
+stats = newest(f"{src}/stats/*/*kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
 allc = {}
