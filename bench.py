@@ -59,11 +59,27 @@ def cpu_baseline(log_n, seconds):
         if el >= seconds or reps >= 200:
             break
     assert (x2 == x).all()
+    # all-cores variant: one independent transform stream per worker PROCESS (never fork a process that has
+    # initialised the GPU: plain child interpreters), a few seconds each
+    import shutil
+    import subprocess
+    workers = min(os.cpu_count() or 1, 64)
+    code = ("import sys,time;sys.path.insert(0,%r);import oracle;n=1<<%d;x=oracle.splitmix(n,7);t0=time.perf_counter();r=0\n"
+            "while time.perf_counter()-t0<%f:\n y=oracle.ntt(x);x=oracle.intt(y);r+=1\n"
+            "print(r,time.perf_counter()-t0)") % (ROOT, log_n, max(2.0, seconds / 3))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(workers)]
+    tot = 0.0
+    for p in procs:
+        o = p.communicate()[0].split()
+        if len(o) == 2:
+            tot += 2 * int(o[0]) * n / float(o[1])
     return {
         "value": 2 * reps * n / el, "unit": "elements/s", "cores": 1, "kind": "port",
         "sample": f"{reps} x (forward + inverse) NTT n=2^{log_n} on 1 thread, {el:.1f} s; oracle/toyni_oracle.c "
                   f"(reference algorithm src/ntt.rs:24-66; the Rust reference itself cannot be built here)",
         "host_cpus": os.cpu_count(),
+        "all_cores": {"value": tot, "unit": "elements/s", "cores": workers, "note": "one independent transform stream per process"},
+        "rust_toolchain_present": shutil.which("cargo") is not None,
     }
 
 
