@@ -297,6 +297,21 @@ def main():
             th = (time.perf_counter() - t0h) / reps_h
             extras[f"host_slice_n2^{ln}"] = {"ms": th * 1e3, "elements_per_s": nn / th, "note": "ntt_cuda-shaped call: H2D u64 + kernels + D2H u64, pageable host memory"}
             c1.destroy()
+        # ---- the other headline size, batched: 64 x n = 2^24 (4 GiB, three sweeps per transform)
+        c24 = toyni_amd.NttContext(1 << 24, device=dev.index)
+        n24, b24 = 1 << 24, 64
+        buf24 = data[: n24 * b24] if data.numel() >= n24 * b24 else torch.randint(0, P, (n24 * b24,), dtype=torch.int32, device=dev)
+        p24 = buf24.data_ptr()
+
+        def fb24():
+            c24.run_device(p24, p24, b24, False, stream=stream)
+            c24.run_device(p24, p24, b24, True, stream=stream)
+
+        t24 = time_dev(fb24, 5)
+        extras["batched_n2^24"] = {"batch": b24, "ms_per_fwd_inv": t24 * 1e3, "elements_per_s": 2 * b24 * n24 / t24,
+                                   "passes_per_transform": c24.passes, "note": "same step as `value` at n = 2^24"}
+        c24.destroy()
+
         # ---- prover-shaped sequence (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident: the NTT /
         #      fold work of one proof: interpolate (INTT 2^16), coset LDE (zero-pad + coset FFT 2^21), the two coset INTTs of
         #      src/fibonacci.rs:145,151, and the 17 FRI folds 2^21 -> 2^4 (src/fibonacci.rs:220-245).  Merkle/transcript and

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Throughput of the device-resident forward transform for every size 2^4 .. 2^27 at about 1 GiB of data per launch
+sequence (batch = 2^28 / n).  Prints one line per size: passes, ms, elements/s, actual GB/s moved (8 B/element/pass)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import toyni_amd  # noqa: E402
+
+P = 2013265921
+TOTAL = 1 << 28
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    data = torch.randint(0, P, (TOTAL,), dtype=torch.int32, device=dev)
+    ptr = data.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    for log_n in range(4, 28):
+        n = 1 << log_n
+        batch = TOTAL // n
+        ctx = toyni_amd.NttContext(n)
+        f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
+        f(); f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        a.record()
+        for _ in range(reps):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        print(f"n=2^{log_n:<2d} batch={batch:<9d} passes={ctx.passes} {ms:8.3f} ms  {TOTAL / ms / 1e6:8.1f} Gelem/s  "
+              f"{8.0 * ctx.passes * TOTAL / ms / 1e9:7.2f} TB/s moved", flush=True)
+        ctx.destroy()
+
+
+if __name__ == "__main__":
+    main()
