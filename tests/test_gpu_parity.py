@@ -163,7 +163,8 @@ def test_edge_vectors_n20(ta):
 
 
 # ---------------------------------------------------------------- batches, chunks, entry-point forms
-@pytest.mark.parametrize("log_n,batch", [(1, 1), (3, 70), (5, 257), (6, 33), (8, 19), (10, 9), (11, 5), (16, 5), (21, 2)])
+# (20, 5) runs the 1024-point passes on 16-wide tiles, (20, 18) on 32-wide, (19, 3) / batch 1 on 8-wide
+@pytest.mark.parametrize("log_n,batch", [(1, 1), (3, 70), (5, 257), (6, 33), (8, 19), (10, 9), (11, 5), (16, 5), (19, 3), (20, 5), (20, 18), (21, 2)])
 def test_batched_device_resident(ta, log_n, batch):
     n = 1 << log_n
     x = oracle.splitmix(n * batch, 7 + log_n).reshape(batch, n)
