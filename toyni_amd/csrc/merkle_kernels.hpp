@@ -14,6 +14,14 @@
 namespace toyni {
 
 TOYNI_HD uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+// three-input XOR: one v_bitop3_b32 on gfx950 (the compiler emits two v_xor for a ^ b ^ c)
+TOYNI_HD uint32_t sha_xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
 TOYNI_HD uint32_t sha_bswap(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24); }
 
 struct Sha256State { uint32_t h[8]; };
@@ -36,12 +44,12 @@ TOYNI_HD void sha256_compress(Sha256State& st, uint32_t (&w)[16]) {
     for (int i = 0; i < 64; ++i) {
         if (i >= 16) {
             const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            const uint32_t s0 = sha_xor3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+            const uint32_t s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        const uint32_t t1 = h + (sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
-        const uint32_t t2 = (sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = h + sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
+        const uint32_t t2 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     st.h[0] += a; st.h[1] += b; st.h[2] += c; st.h[3] += d; st.h[4] += e; st.h[5] += f; st.h[6] += g; st.h[7] += h;
