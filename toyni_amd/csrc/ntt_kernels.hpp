@@ -4,7 +4,7 @@
 // (cuda/ntt_kernel.cu:103-113), log2(n) x ntt_kernel_butterfly (:119-137) and scale_by_inv_n
 // (:140-143) -- i.e. (log2 n + 1) full HBM sweeps per transform.  Here a transform of size
 // n = M_1 * ... * M_P (P <= 3, M_p <= 1024) is P sweeps; no bit-reversal pass exists (the digit
-// reversal is absorbed in the last pass' store addressing) and n^-1 is folded into a twiddle table.
+// reversal is absorbed in the last pass' store addressing) and n^-1 rides on the first pass' twiddle seed.
 //
 // Decomposition (decimation in frequency, natural order in and out; same values as src/ntt.rs:24-53):
 //   input index  j = j_1 * n/M_1 + j_2 * n/(M_1 M_2) + ...      (j_1 most significant)
@@ -20,13 +20,14 @@
 //           C or E2 consecutive words), runs the LE1 high-bit radix-2 Gentleman-Sande stages in
 //           registers, and parks the tile in LDS;
 //   step 2: each thread reads groups of E2 = 2^LE2 elements back (a different lane<->element map),
-//           runs the LE2 low-bit stages with wave-uniform twiddles (scalar loads), applies the
+//           runs the LE2 low-bit stages with wave-uniform twiddles (held in SGPRs), applies the
 //           inter-pass twiddle / scale and stores straight to HBM.
 // So a pass touches HBM once each way and LDS once each way.  Passes with M <= 32 are single-step and
 // use no LDS.  No MFMA: this is integer modular arithmetic (64 lanes x 32-bit VALU).
 //
-// The bodies take (block id, thread id, LDS pointer) explicitly and contain no HIP builtins, so
-// tests/emu steps exactly this code on the CPU against the oracle.
+// The bodies take (tile id, thread id, LDS pointer) explicitly; the few device-only hooks (scheduling fences, wait
+// counts, readfirstlane) are macros that vanish on the host, so tests/emu steps exactly this code on the CPU against
+// the oracle (also under ASan/UBSan).
 #pragma once
 #include "bb_field.hpp"
 
