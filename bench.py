@@ -239,6 +239,21 @@ def main():
                 for k, v in tj["kernels"].items():
                     if want in k:
                         traffic, traffic_src = v["hbm_bytes_per_launch"], f"profiles/r01_traffic.json ({k.split('(')[0]})"
+        # The binding resource is VALU issue, not HBM: report it next to the required HBM object.
+        # instructions/element from the committed rocprofv3 SQ_INSTS_VALU of the same command; peak = 256 CUs x 4 SIMDs x
+        # 64 lanes / 4 cycles x 2.4 GHz = 39.3 T lane-ops/s (measured with `--microbench`: integer multiplies issue at the add rate)
+        valu = None
+        cfile = os.path.join(ROOT, "profiles", "r01_counters.json")
+        if os.path.exists(cfile) and traffic is not None:
+            cj = json.load(open(cfile))
+            per_launch = {("Pass<0" if "Pass<0" in k else "Pass<1"): v.get("SQ_INSTS_VALU") for k, v in cj.items() if "ntt_pass_kernel" in k and "5, 5, 5>" in k}
+            if all(per_launch.get(x) for x in ("Pass<0", "Pass<1")):
+                lane_ops_per_elem = (per_launch["Pass<0"] + per_launch["Pass<1"]) * 64.0 / (n * batch)
+                t_fwd = sum(fwd_ms) * 1e-3
+                ach = lane_ops_per_elem * n * batch / t_fwd / 1e12
+                valu = {"lane_ops_per_element_per_transform": lane_ops_per_elem, "achieved_Tops": ach, "peak_Tops": 39.3,
+                        "frac": ach / 39.3, "note": "forward transform; sustained clock under this load is ~2.0 GHz (GRBM_GUI_ACTIVE), "
+                                                    "i.e. ~0.84 of the issue rate at that clock"}
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,
@@ -247,6 +262,7 @@ def main():
             "all_pass_ms": {"forward": fwd_ms, "inverse": inv_ms},
             "kernel_stream_GBps": 8.0 * n * batch / (fwd_ms[dom] * 1e-3) / 1e9,
             "transform_algorithmic_GBps": 8.0 * n * batch / (sum(fwd_ms) * 1e-3) / 1e9,
+            "valu": valu,
         }
 
     # ---- side measurements (not `value`) ----
