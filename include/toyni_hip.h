@@ -71,6 +71,10 @@ int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);
  * H2D -> narrow -> fused passes -> widen -> D2H. */
 int toyni_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, int inverse);
 
+/* The same over several GPUs from ONE host process: the batch is sharded contiguously over `devices` (ordinals; a
+ * device may be listed more than once), one host thread and one context per entry, no collective.  Blocking. */
+int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t* h_data, size_t batch, int inverse);
+
 /* Device-resident, packed u32, in place (d_in == d_out) or out of place.  Enqueued on `stream`
  * (a hipStream_t; NULL = HIP's default stream, as everywhere in HIP) and NOT synchronised: this is the
  * entry point the roofline numbers are measured on.  batch transforms are contiguous (stride n).

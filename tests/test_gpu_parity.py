@@ -539,3 +539,19 @@ def test_ext_transform_single_call(ta, log_n, shift):
     ctx.synchronize()
     assert (buf.download(np.uint32, 4 * n).reshape(n, 4) == evals).all()
     buf.free()
+
+
+def test_single_process_multi_gpu_batch_runner(ta):
+    # toyni_ntt_host_multi_gpu: contiguous shards, one host thread + context per listed device.  One GPU here, so the
+    # device is listed three times: the sharding (ragged: 7 = 3 + 2 + 2), the threads and the per-device contexts all run.
+    n, batch = 1 << 12, 7
+    x = oracle.splitmix(n * batch, 606)
+    v = x.copy()
+    devs = (ctypes.c_int * 3)(0, 0, 0)
+    rc = ta._lib.lib.toyni_ntt_host_multi_gpu(devs, 3, n, v.ctypes.data, batch, 0)
+    assert rc == 0, ta._lib.error_string(rc)
+    assert (v.reshape(batch, n) == np.stack([oracle.ntt(r) for r in x.reshape(batch, n)])).all()
+    rc = ta._lib.lib.toyni_ntt_host_multi_gpu(devs, 3, n, v.ctypes.data, batch, 1)
+    assert rc == 0 and (v == x).all()
+    bad = (ctypes.c_int * 1)(99)
+    assert ta._lib.lib.toyni_ntt_host_multi_gpu(bad, 1, n, v.ctypes.data, 1, 0) == 10006   # TOYNI_E_RANGE: no such device

@@ -66,6 +66,7 @@ SIGNATURES = {
     "toyni_ntt_ctx_passes": (c_int, [c_void_p]),
     "toyni_ntt_ctx_set_chunk": (c_int, [c_void_p, c_size]),
     "toyni_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_int]),
+    "toyni_ntt_host_multi_gpu": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_size, c_int]),
     "toyni_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_int, c_void_p]),
     "toyni_ntt_device_u64": (c_int, [c_void_p, c_void_p, c_size, c_int, c_void_p]),
     "toyni_coset_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_int, c_void_p]),

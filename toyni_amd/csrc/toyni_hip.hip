@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/toyni_hip.h"
@@ -591,6 +592,35 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
 }
 
 int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse) { return host_transform(c, h_data, batch, 1u, inverse); }
+
+// Single-process multi-GPU form of the batched host-slice transform (for a host like Toyni, which is one process):
+// the batch is sharded contiguously over the listed devices, one host thread + one context per device, no collective.
+// (The benchmark's scaling runs use one PROCESS per GPU instead: bench.py / toyni_amd/dist.py.)
+int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t* h_data, size_t batch, int inverse) {
+    if (!devices || !h_data) return TOYNI_E_NULL;
+    if (ndev < 1) return TOYNI_E_RANGE;
+    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    std::vector<int> status((size_t)ndev, TOYNI_OK);
+    std::vector<std::thread> workers;
+    const size_t base = batch / (size_t)ndev, rem = batch % (size_t)ndev;
+    size_t start = 0;
+    for (int d = 0; d < ndev; ++d) {
+        const size_t count = base + ((size_t)d < rem ? 1 : 0);
+        const size_t first = start;
+        start += count;
+        workers.emplace_back([&, d, first, count]() {
+            if (count == 0) return;
+            toyni_ntt_ctx* ctx = nullptr;
+            int rc = toyni_ntt_ctx_create(n, devices[d], &ctx);
+            if (rc == TOYNI_OK) rc = toyni_ntt_host(ctx, h_data + first * (size_t)n, count, inverse);
+            (void)toyni_ntt_ctx_destroy(ctx);
+            status[(size_t)d] = rc;
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int rc : status) if (rc != TOYNI_OK) return rc;
+    return TOYNI_OK;
+}
 
 // fft_ext / ifft_ext (src/math/domain.rs:129-151): one call, one PCIe round trip, the four coordinate transforms as ONE batch of 4
 int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int inverse) {
