@@ -377,6 +377,23 @@ def main():
             extras["prover_shape_trace2^16_lde2^21"]["hipgraph_replay_us"] = None
             extras["prover_shape_trace2^16_lde2^21"]["hipgraph_error"] = str(exc)[:200]
 
+        # ---- BASELINE configs[2]: the whole prover-shaped harness (tests/harness/fib_prover.py) at trace_len 2^16, blowup 32:
+        #      GPU LDE + coset INTTs + 17 folds + 20 Merkle trees + transcript + 44 query openings; host work (OOD Horner,
+        #      hashing the transcript, path extraction) included.  The proof is checked by the verifier restatement in tests.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from harness import fib_prover
+            col = fib_prover.fibonacci_trace(1 << 16)
+            fib_prover.generate_proof(col, seed=11)            # warm (contexts, tables)
+            torch.cuda.synchronize()
+            t0p = time.perf_counter()
+            fib_prover.generate_proof(col, seed=12)
+            torch.cuda.synchronize()
+            extras["fib_prove_trace2^16_blowup32"] = {"ms": (time.perf_counter() - t0p) * 1e3,
+                                                      "note": "harness wall time, one proof, warm; the reference prover is infeasible at this size (O(n^3) interpolation, SURVEY F5)"}
+        except Exception as exc:
+            extras["fib_prove_trace2^16_blowup32"] = {"ms": None, "error": str(exc)[:200]}
+
         # Merkle commitment of one lde-size layer (the prover builds 3 of these plus 17 shrinking FRI layers): SURVEY 8(f) rank 2
         from toyni_amd._lib import lib as _tlib
         nl = 1 << ll
