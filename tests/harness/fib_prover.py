@@ -94,16 +94,15 @@ def derive_z(tr: Transcript, lde_size: int) -> int:
             return z
 
 
-def horner_host(coeffs: np.ndarray, z: int) -> int:
-    """sum c_i z^i with vectorised power doubling (uint64 products < 2^62)."""
-    n = coeffs.size
-    pw = np.ones(1, dtype=np.uint64)
+def poly_eval(coeffs: torch.Tensor, z: int) -> int:
+    """sum c_i z^i on the device (int64 tensor of coefficients): powers by doubling, products < 2^62, partial sums < 2^53."""
+    n = coeffs.numel()
+    pw = torch.ones(1, dtype=torch.int64, device=coeffs.device)
     step = z % P
-    while pw.size < n:
-        pw = np.concatenate([pw, (pw * np.uint64(step)) % np.uint64(P)])
+    while pw.numel() < n:
+        pw = torch.cat([pw, mulmod(pw, step)])
         step = step * step % P
-    pw = pw[:n]
-    return int(((coeffs.astype(np.uint64) * pw) % np.uint64(P)).sum(dtype=np.uint64) % np.uint64(P))
+    return int((mulmod(coeffs, pw[:n]).sum() % P).item())
 
 
 class DeviceTree:
@@ -116,7 +115,7 @@ class DeviceTree:
         self.salts = None
         d_salts = 0
         if salted:
-            self.salts = torch.from_numpy(rng.integers(0, 256, (n, 16), dtype=np.uint8)).to(values_i32.device)
+            self.salts = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device=values_i32.device, generator=rng)
             d_salts = self.salts.data_ptr()
         total = _lib.toyni_merkle_total_digests(n)
         self.levels = torch.empty((total, 32), dtype=torch.uint8, device=values_i32.device)
@@ -132,24 +131,34 @@ class DeviceTree:
     def root(self) -> bytes:
         return bytes(self.levels[-1].cpu().numpy().tobytes())
 
+    def open_many(self, indices):
+        """open_merkle (src/fibonacci.rs:366-375) + MerkleTree::get_proof (src/merkle.rs:50-80) for a list of positions:
+        ONE gather of all path digests / values / salts on the device, one copy to the host."""
+        rows, positions = [], []
+        for index in indices:
+            pos, cur = [], index
+            for off, m in self.offsets[:-1]:
+                sib = cur + 1 if cur % 2 == 0 else cur - 1
+                if sib >= m:
+                    rows.append(off + cur)
+                    pos.append(True)
+                else:
+                    rows.append(off + sib)
+                    pos.append(cur % 2 == 1)
+                cur //= 2
+            positions.append(pos)
+        dev = self.levels.device
+        idx_t = torch.tensor(list(indices), dtype=torch.long, device=dev)
+        depth = len(self.offsets) - 1
+        paths = self.levels[torch.tensor(rows, dtype=torch.long, device=dev)].cpu().numpy().reshape(len(indices), depth, 32) if rows \
+            else np.zeros((len(indices), 0, 32), np.uint8)
+        vals = self.values[idx_t].cpu().numpy()
+        salts = self.salts[idx_t].cpu().numpy() if self.salts is not None else None
+        return [{"index": index, "value": int(vals[k]), "path": [p.tobytes() for p in paths[k]], "position": positions[k],
+                 "salt": salts[k].tobytes() if salts is not None else b""} for k, index in enumerate(indices)]
+
     def open(self, index: int):
-        """open_merkle (src/fibonacci.rs:366-375) + MerkleTree::get_proof (src/merkle.rs:50-80)."""
-        rows, position, cur = [], [], index
-        for off, m in self.offsets[:-1]:
-            sib = cur + 1 if cur % 2 == 0 else cur - 1
-            if sib >= m:
-                rows.append(off + cur)
-                position.append(True)
-            else:
-                rows.append(off + sib)
-                position.append(cur % 2 == 1)
-            cur //= 2
-        path = self.levels[torch.tensor(rows, dtype=torch.long, device=self.levels.device)].cpu().numpy() if rows else np.zeros((0, 32), np.uint8)
-        return {
-            "index": index, "value": int(self.values[index].item()),
-            "path": [p.tobytes() for p in path], "position": position,
-            "salt": bytes(self.salts[index].cpu().numpy().tobytes()) if self.salts is not None else b"",
-        }
+        return self.open_many([index])[0]
 
 
 def fibonacci_trace(n: int) -> np.ndarray:
@@ -162,10 +171,21 @@ def fibonacci_trace(n: int) -> np.ndarray:
     return out
 
 
-def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None):
+def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, timing: dict = None):
+    import time
     dev = torch.device("cuda", 0)
+    _t = [time.perf_counter()]
+
+    def lap(name):
+        if timing is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + (now - _t[0]) * 1e3
+            _t[0] = now
+
     stream = torch.cuda.current_stream().cuda_stream
-    rng = np.random.default_rng(seed)
+    rng = torch.Generator(device=dev)       # salts and mask coefficients (the reference uses rand::thread_rng)
+    rng.manual_seed(seed)
     n = int(trace_col.size)
     assert n & (n - 1) == 0
     log_n = n.bit_length() - 1
@@ -181,16 +201,17 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None):
     # ---- 1. trace polynomial + masking (src/fibonacci.rs:110-121): T_hat = T + (x^n - 1) R ----
     coeffs = torch.from_numpy(trace_col.astype(np.int32)).to(dev)
     ntt_dev(ctx_n, coeffs, True)                                   # interpolate: one INTT
-    r = torch.from_numpy(rng.integers(0, P, MASK_DEGREE, dtype=np.int64)).to(dev)
+    r = torch.randint(0, P, (MASK_DEGREE,), dtype=torch.int64, device=dev, generator=rng)
     poly = torch.zeros(N, dtype=torch.int64, device=dev)
     poly[:n] = coeffs.to(torch.int64)
     poly[:MASK_DEGREE] = (poly[:MASK_DEGREE] - r) % P
     poly[n:n + MASK_DEGREE] = (poly[n:n + MASK_DEGREE] + r) % P
-    trace_poly = poly.cpu().numpy().astype(np.uint64)              # coefficients, for the OOD evaluations
+    trace_poly = poly[: n + MASK_DEGREE].clone()                  # coefficients, for the OOD evaluations
     trace_lde = poly.to(torch.int32)
     ntt_dev(ctx_N, trace_lde, False, shift=COSET_SHIFT)            # LDE: one coset FFT
     trace_tree = DeviceTree(trace_lde, rng, True, stream)
     trace_commitment = trace_tree.root()
+    lap("1_interpolate_mask_lde_commit")
 
     # x_i = 7 w_N^i: the coset FFT of the polynomial "x"
     xs32 = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -214,25 +235,29 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None):
     q32 = q_evals.to(torch.int32)
     q_poly_t = q32.clone()
     ntt_dev(ctx_N, q_poly_t, True, shift=COSET_SHIFT)              # ifft #2
-    q_poly = q_poly_t.cpu().numpy().astype(np.uint64)
+    q_poly = q_poly_t.to(torch.int64)
     quotient_tree = DeviceTree(q32, rng, True, stream)
     quotient_commitment = quotient_tree.root()
+    lap("2_constraint_quotient_commit")
 
     # ---- 3./4. Fiat-Shamir, OOD evaluations (src/fibonacci.rs:155-183) ----
     tr = Transcript()
     tr.absorb(trace_commitment)
     tr.absorb(quotient_commitment)
     z = derive_z(tr, N)
-    t_z, t_gz, t_ggz = horner_host(trace_poly, z), horner_host(trace_poly, g * z % P), horner_host(trace_poly, g * g % P * z % P)
-    q_z = horner_host(q_poly, z)
+    t_z, t_gz, t_ggz = poly_eval(trace_poly, z), poly_eval(trace_poly, g * z % P), poly_eval(trace_poly, g * g % P * z % P)
+    q_z = poly_eval(q_poly, z)
     c_z = (t_ggz - t_gz - t_z) % P * ((z - pow(g, n - 1, P)) % P) % P * ((z - pow(g, n - 2, P)) % P) % P
     assert c_z == q_z * ((pow(z, n, P) - 1) % P) % P, "Constraint check at z failed"      # src/fibonacci.rs:173-177
     for v in (t_z, t_gz, t_ggz, q_z):
         tr.absorb_field(v)
+    lap("3_transcript_ood")
 
     # ---- 5. DEEP layer (src/fibonacci.rs:186-198) ----
     inv_xz = invmod_t((xs - z) % P)
     d_evals = mulmod(((q_evals - q_z) + (T_gg - t_ggz) + (T_g - t_gz) + (T - t_z)) % P, inv_xz)
+
+    lap("5_deep")
 
     # ---- 6. FRI: fold + commit (src/fibonacci.rs:200-247) ----
     bound = 1 << (n + MASK_DEGREE - 1).bit_length()               # next_power_of_two
@@ -254,28 +279,31 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None):
         commitments.append(trees[-1].root())
         tr.absorb(commitments[-1])
     final_layer = [int(v) for v in layers[-1].cpu().numpy()]
+    lap("6_fri_fold_commit")
 
     # ---- 7. queries (src/fibonacci.rs:249-295) ----
     half0 = N // 2
+    qidx = tr.squeeze_indices(NUM_QUERIES, half0)
+    t_open = trace_tree.open_many([i for qi in qidx for i in (qi, (qi + BLOWUP) % N, (qi + 2 * BLOWUP) % N)])
+    q_open = quotient_tree.open_many(qidx)
+    d_open = trees[0].open_many([i for qi in qidx for i in (qi, qi + half0)])
+    fri_open = []                                   # per intermediate layer: openings of (idx, idx + half) for every query
+    cur_idx = list(qidx)
+    for li in range(1, len(layers) - 1):
+        half = layers[li].numel() // 2
+        cur_idx = [i % half for i in cur_idx]
+        fri_open.append(trees[li].open_many([j for i in cur_idx for j in (i, i + half)]))
     query_proofs = []
-    for qi in tr.squeeze_indices(NUM_QUERIES, half0):
-        qp = {
+    for k, qi in enumerate(qidx):
+        query_proofs.append({
             "index": qi,
-            "trace_opening": trace_tree.open(qi),
-            "trace_opening_g": trace_tree.open((qi + BLOWUP) % N),
-            "trace_opening_gg": trace_tree.open((qi + 2 * BLOWUP) % N),
-            "quotient_opening": quotient_tree.open(qi),
-            "deep_opening": trees[0].open(qi),
-            "deep_opening_pair": trees[0].open(qi + half0),
-            "fri_openings": [],
-        }
-        idx = qi
-        for li in range(1, len(layers) - 1):
-            half = layers[li].numel() // 2
-            idx %= half
-            qp["fri_openings"].append((trees[li].open(idx), trees[li].open(idx + half)))
-        query_proofs.append(qp)
+            "trace_opening": t_open[3 * k], "trace_opening_g": t_open[3 * k + 1], "trace_opening_gg": t_open[3 * k + 2],
+            "quotient_opening": q_open[k],
+            "deep_opening": d_open[2 * k], "deep_opening_pair": d_open[2 * k + 1],
+            "fri_openings": [(lo[2 * k], lo[2 * k + 1]) for lo in fri_open],
+        })
 
+    lap("7_queries")
     if stats is not None:
         stats.update({"n": n, "lde": N, "folds": len(layers) - 1, "final_layer_size": final_size})
     return {
