@@ -97,3 +97,13 @@ def test_full_size_prove_trace_2_16(prover):
     why = []
     assert fib_verifier.verify(proof, why), why
     assert len(proof["query_proofs"]) == 44 and len(proof["query_proofs"][0]["fri_openings"]) == 16
+
+
+def test_trace_len_8_the_readme_table(prover):
+    # BASELINE configs[0] names trace_len 8 (the README's 8-row illustration): lde 256, degree bound 256,
+    # 8 folds down to a single-element final layer
+    stats = {}
+    proof = prover.generate_proof(prover.fibonacci_trace(8), seed=8, stats=stats)
+    assert stats == {"n": 8, "lde": 256, "folds": 8, "final_layer_size": 1}
+    why = []
+    assert fib_verifier.verify(proof, why), why
