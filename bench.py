@@ -266,7 +266,7 @@ def main():
         }
 
     # ---- side measurements (not `value`) ----
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and world == 1:  # side measurements only on the single-GPU run
         extras = {}
 
         def time_dev(fn, reps):
