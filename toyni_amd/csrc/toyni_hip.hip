@@ -271,6 +271,35 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const Digest* __restr
     }
 }
 
+// All remaining levels of a tree whose current level has m <= MERKLE_TAIL digests, in ONE workgroup: the level lives in
+// LDS, each round halves it (odd rounds duplicate the last node) and is also written to global memory (the proofs need
+// every level).  Replaces ~log2(m) tiny launches per tree -- the FRI layers of a proof are mostly trees this small.
+constexpr uint32_t MERKLE_TAIL = 1024;
+__global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m) {
+    __shared__ Digest lvl[MERKLE_TAIL];
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
+    __syncthreads();
+    while (m > 1) {
+        const uint32_t up = (m + 1) / 2;
+        Digest mine[MERKLE_TAIL / 2 / 256];
+        uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < up; i += blockDim.x) {
+            const Digest l = lvl[2 * i];
+            const Digest r = (2 * i + 1 < m) ? lvl[2 * i + 1] : l;
+            mine[cnt++] = merkle_node(l, r);
+        }
+        __syncthreads();  // every read of the old level is done
+        cnt = 0;
+        for (uint32_t i = threadIdx.x; i < up; i += blockDim.x) {
+            lvl[i] = mine[cnt];
+            next[i] = mine[cnt++];
+        }
+        __syncthreads();
+        next += up;
+        m = up;
+    }
+}
+
 // instruction-throughput probe (8 independent chains per lane)
 template <int WHICH>
 __global__ void __launch_bounds__(256) microbench_kernel(uint32_t seed, int iters, uint32_t* sink) {
@@ -863,12 +892,13 @@ int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts,
     Digest* cur = reinterpret_cast<Digest*>(d_levels);
     hipLaunchKernelGGL(merkle_leaf_kernel, dim3(grid_for(n)), dim3(256), 0, s, d_values, reinterpret_cast<const uint4*>(d_salts), cur, n);
     size_t m = n;
-    while (m > 1) {
+    while (m > MERKLE_TAIL) {
         const size_t up = (m + 1) / 2;
         hipLaunchKernelGGL(merkle_level_kernel, dim3(grid_for(up)), dim3(256), 0, s, (const Digest*)cur, cur + m, m, up);
         cur += m;
         m = up;
     }
+    if (m > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(256), 0, s, (const Digest*)cur, cur + m, (uint32_t)m);
     return (int)hipGetLastError();
 }
 
