@@ -146,6 +146,52 @@ def main():
     assert len(set(layers[-1])) == 1
     out["fold_layers"] = {"n": N, "shift": shift, "betas": betas, "evals": evals, "layers": layers}
 
+    # Ext = F_p[X]/(X^4 - 11) fold (src/math/fri.rs:7-25, src/ext.rs:138-192), independent schoolbook model on Python ints
+    def ext_mul(a, b):
+        t = [0] * 7
+        for i in range(4):
+            for j in range(4):
+                t[i + j] = (t[i + j] + a[i] * b[j]) % P
+        return [(t[k] + 11 * t[k + 4]) % P if k + 4 < 7 else t[k] % P for k in range(4)]
+
+    ext_cases = []
+    for name, N, shift, seed in [("ext_fold_n8_shift7", 8, 7, 1), ("ext_fold_n64_shift7", 64, 7, 2), ("ext_fold_n2", 2, 7, 3)]:
+        flat = rnd(4 * N, 0xE47F01D0 + seed)
+        evals = [flat[4 * i:4 * i + 4] for i in range(N)]
+        beta = rnd(4, 0xBE7AE47 + seed)
+        w = root(N.bit_length() - 1)
+        xs = [(shift * pow(w, i, P)) % P for i in range(N)]
+        half_inv = pow(2, P - 2, P)
+        folded = []
+        for i in range(N // 2):
+            a, b = evals[i], evals[i + N // 2]
+            avg = [(x + y) * half_inv % P for x, y in zip(a, b)]
+            diff = [(x - y) * half_inv % P for x, y in zip(a, b)]
+            prod = ext_mul(ext_mul(diff, beta), [pow(xs[i], P - 2, P), 0, 0, 0])
+            folded.append([(u + v) % P for u, v in zip(avg, prod)])
+        ext_cases.append({"name": name, "n": N, "xs": xs, "beta": beta, "evals": evals, "folded": folded})
+    # X^4 = 11 and a product known by hand: (1 + X)(1 + X^3) = 1 + X + X^3 + X^4 = 12 + X + X^3
+    out["ext"] = {"x4": ext_mul([0, 0, 1, 0], [0, 0, 1, 0]), "hand_product": ext_mul([1, 1, 0, 0], [1, 0, 0, 1]), "fold": ext_cases}
+    assert out["ext"]["x4"] == [11, 0, 0, 0] and out["ext"]["hand_product"] == [12, 1, 0, 1]
+
+    # SHA-256 Merkle roots (src/merkle.rs, src/fibonacci.rs:340-361) from hashlib
+    import hashlib
+    def hl(b):
+        return hashlib.sha256(b).digest()
+    def root_of(leaves):
+        cur = [hl(b"\x00" + l) for l in leaves]
+        while len(cur) > 1:
+            cur = [hl(b"\x01" + cur[i] + (cur[i + 1] if i + 1 < len(cur) else cur[i])) for i in range(0, len(cur), 2)]
+        return cur[0].hex()
+    mk = []
+    for n_leaves in (1, 2, 3, 4, 7, 64):
+        vals = rnd(n_leaves, 0x3E2C1E + n_leaves)
+        salts = [bytes((17 * i + 13 * j + n_leaves) & 0xFF for j in range(16)) for i in range(n_leaves)]
+        mk.append({"n": n_leaves, "values": vals, "salts_hex": [s_.hex() for s_ in salts],
+                   "root_unsalted": root_of([v.to_bytes(8, "little") for v in vals]),
+                   "root_salted": root_of([s_ + v.to_bytes(8, "little") for s_, v in zip(salts, vals)])})
+    out["merkle"] = mk
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

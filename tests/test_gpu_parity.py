@@ -555,3 +555,12 @@ def test_single_process_multi_gpu_batch_runner(ta):
     assert rc == 0 and (v == x).all()
     bad = (ctypes.c_int * 1)(99)
     assert ta._lib.lib.toyni_ntt_host_multi_gpu(bad, 1, n, v.ctypes.data, 1, 0) == 10006   # TOYNI_E_RANGE: no such device
+
+
+def test_fold_ext_and_merkle_golden(ta, golden):
+    for c in golden["ext"]["fold"]:
+        assert ta.fri_fold_ext(np.array(c["evals"], dtype=np.uint64), c["xs"], c["beta"]).tolist() == c["folded"], c["name"]
+    for c in golden["merkle"]:
+        salts = np.frombuffer(b"".join(bytes.fromhex(s) for s in c["salts_hex"]), dtype=np.uint8).reshape(c["n"], 16)
+        assert ta.MerkleTree(c["values"]).root().hex() == c["root_unsalted"]
+        assert ta.MerkleTree(c["values"], salts).root().hex() == c["root_salted"]

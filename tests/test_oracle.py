@@ -189,3 +189,18 @@ def test_fold_ext_is_coordinatewise_linear_with_x4_eq_11():
         d = [(x - y) * hi % P for x, y in zip(a, b)]
         dx = [11 * d[3] % P, d[0], d[1], d[2]]
         assert out[i].tolist() == [(avg[k] + dx[k] * xinv) % P for k in range(4)]
+
+
+def test_fold_ext_golden(golden):
+    # independent schoolbook model of Ext = F_p[X]/(X^4 - 11) (tests/golden/gen_golden.py)
+    assert golden["ext"]["x4"] == [11, 0, 0, 0]
+    for c in golden["ext"]["fold"]:
+        got = oracle.fri_fold_ext(np.array(c["evals"], dtype=np.uint64), c["xs"], c["beta"])
+        assert got.tolist() == c["folded"], c["name"]
+
+
+def test_merkle_golden(golden):
+    for c in golden["merkle"]:
+        salts = np.frombuffer(b"".join(bytes.fromhex(s) for s in c["salts_hex"]), dtype=np.uint8).reshape(c["n"], 16)
+        assert oracle.merkle_commit_values(c["values"], None)[-1][0].tobytes().hex() == c["root_unsalted"]
+        assert oracle.merkle_commit_values(c["values"], salts)[-1][0].tobytes().hex() == c["root_salted"]
