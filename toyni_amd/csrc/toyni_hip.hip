@@ -381,13 +381,12 @@ int grid_for(size_t items, int block = 256) {
 }
 
 // prefetch variants (TOYNI_PREFETCH = 0 | 32: none / the whole next tile; tuning knob, 32 is the measured default)
-static int g_prefetch = -1;
-static int prefetch_depth() {
-    if (g_prefetch < 0) {
-        g_prefetch = 32;
-        if (const char* env = std::getenv("TOYNI_PREFETCH")) g_prefetch = std::atoi(env);
-    }
-    return g_prefetch;
+int prefetch_depth() {
+    static const int depth = [] {
+        const char* env = std::getenv("TOYNI_PREFETCH");
+        return env ? std::atoi(env) : 32;
+    }();
+    return depth;
 }
 
 template <class P>
@@ -400,23 +399,22 @@ void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntile
 // count; TOYNI_WG_PER_CU overrides the occupancy query (tuning knob).
 template <class P>
 unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
-    static int per_cu = 0;  // per instantiation
-    if (per_cu == 0) {
+    static const int per_cu = [] {  // once per instantiation (thread-safe initialisation)
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0) != hipSuccess || occ < 1) occ = 1;
         if (const char* env = std::getenv("TOYNI_WG_PER_CU")) { int v = std::atoi(env); if (v > 0) occ = v; }
-        per_cu = occ;
-    }
+        return occ;
+    }();
     uint64_t g = (uint64_t)c->num_cus * (uint64_t)per_cu;
     if (g > ntiles) g = ntiles;
     if (g >= 16) g &= ~(uint64_t)15;  // keep the XCD pairing of tile_order aligned across loop iterations
     return (unsigned)(g < 1 ? 1 : g);
 }
 
-// enqueue the passes of `batch` transforms; d_in == d_out allowed
 int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 
-// shift != 1: the coset scaling of BabyBearDomain::fft / ifft is fused into the first / last pass
+// Enqueue the passes of `batch` transforms on stream s (d_in == d_out allowed).  shift != 1: the coset scaling of
+// BabyBearDomain::fft / ifft is fused into the first / last pass.
 int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u) {
     if (batch == 0) return 0;
     const size_t n = c->n;
@@ -471,7 +469,8 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out) {
     st.s[1] = bb_inv_host(shift);  // src/math/domain.rs:167
     for (int dir = 0; dir < 2; ++dir) append_two_level(blob, c->plan.log_n, st.s[dir], 1u, st.lo_off[dir], st.hi_off[dir], st.lowbits);
     HIPCHK(hipMalloc((void**)&st.d, blob.size() * sizeof(uint32_t)));
-    HIPCHK(hipMemcpy(st.d, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipError_t e = hipMemcpy(st.d, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(st.d); return (int)e; }
     auto ins = c->shifts.emplace(shift, st);
     *out = &ins.first->second;
     return 0;
