@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--microbench", action="store_true", help="also print integer-multiply issue rates (stderr)")
-    ap.add_argument("--workload", choices=["batch", "fourstep"], default="batch",
+    ap.add_argument("--workload", choices=["batch", "fourstep", "slab"], default="batch",
                     help="batch: the default sharded batch (weak scaling); fourstep: ONE transform of n = 2^log-n split over "
                          "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit)")
     return ap.parse_args()
@@ -89,13 +89,22 @@ def bench_fourstep(args, dev, rank, world, distributed):
     import torch.distributed as dist
     from toyni_amd import dist as tdist
     log_n = args.log_n
-    l1, l2 = tdist.fourstep_split(log_n, world)
+    slab = args.workload == "slab"   # transpose-free form (include/toyni_hip.h 2b); "fourstep" = the transpose-based one
+    l1, l2 = tdist.slab_split(log_n, world) if slab else tdist.fourstep_split(log_n, world)
     ops = tdist.HipLocalOps(log_n, dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x4057E9 + rank)
     cols = torch.randint(0, P, ((1 << l1), (1 << l2) // world), dtype=torch.int32, device=dev, generator=gen)
 
+    keep = cols.clone()
+
+    state = {"slab": cols}
+
     def step():
+        if slab:                     # both directions overwrite their input; the inverse's result feeds the next step
+            out = tdist.slab_forward(state["slab"], log_n, ops, rank, world)
+            state["slab"] = tdist.slab_inverse(out, log_n, ops, rank, world)
+            return state["slab"]
         out = tdist.fourstep_forward(cols, log_n, ops, rank, world)
         return tdist.fourstep_inverse(out, log_n, ops, rank, world)
 
@@ -112,13 +121,13 @@ def bench_fourstep(args, dev, rank, world, distributed):
         back = step()
     fence()
     wall = tdist.max_over_ranks(time.perf_counter() - t0, dev)
-    assert torch.equal(back, cols), "4-step round trip changed the data"
+    assert torch.equal(back, keep), "round trip changed the data"
     if rank == 0:
         print(json.dumps({
-            "metric": "BabyBear NTT throughput, single transform split over GPUs (4-step, one all-to-all)", "value": 2 * args.steps * (1 << log_n) / wall,
+            "metric": "BabyBear NTT throughput, single transform split over GPUs (%s, one all-to-all)" % ("slab form" if slab else "4-step"), "value": 2 * args.steps * (1 << log_n) / wall,
             "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"forward+inverse 4-step NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
+            "config": {"workload": f"forward+inverse {'slab-form' if slab else '4-step'} NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
                        "log_n": log_n, "parallelism": f"column/row split x{world}, RCCL all-to-all"},
             "roofline": None, "cpu_baseline": None,
         }))
@@ -151,7 +160,7 @@ def main():
         dist.barrier()
     import toyni_amd
 
-    if args.workload == "fourstep":
+    if args.workload in ("fourstep", "slab"):
         return bench_fourstep(args, dev, rank, world, distributed)
 
     n = 1 << args.log_n

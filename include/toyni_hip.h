@@ -103,6 +103,29 @@ int toyni_ntt_ext_device(toyni_ntt_ctx* ctx, uint32_t* d_data, uint32_t shift, i
  * RCCL all-to-all (toyni_amd/dist.py). */
 int toyni_fourstep_twiddle_device(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t rows, size_t row_len, size_t row0, int inverse, void* stream);
 
+/* 2b. One size-n transform over G devices WITHOUT local transposes (one process per GPU; the exchange is the caller's
+ * all-to-all).  View x as [M1][S1], M1 = toyni_ntt_ctx_first_pass_points(ctx) (0 when n <= 1024: nothing to split),
+ * S1 = n / M1.  The transform's first pass couples only elements of one column, so a rank that owns a block of
+ * columns runs it alone (the same strided pass kernel the single-device transform uses); what remains for every k1
+ * is an ordinary size-S1 transform (toyni_ntt_device on a size-S1 context):
+ *   forward: slab pass (twiddle fused) -> all-to-all of contiguous row blocks -> relayout(0) -> size-S1 row transforms
+ *   inverse: size-S1 inverse row transforms -> relayout(1) (twiddle fused) -> all-to-all -> slab pass(inverse)
+ * Four HBM sweeps per direction at n = 2^27 instead of the eight of the transpose-based 4-step above.
+ * Layouts: forward input / inverse output = slab [M1][cols_local], element (j1, c) = x[j1 S1 + col_base + c];
+ *          forward output / inverse input = rows [rows_local][S1], element (r, k') = X[(row0 + r) + M1 k'].
+ * cols_local and rows_local are powers of two, cols_local >= 32.  (src/ntt.rs:11-81 has no multi-device form: values
+ * are pinned by the single-device transform and the oracle on the gathered result.) */
+size_t toyni_ntt_ctx_first_pass_points(const toyni_ntt_ctx* ctx);
+/* in place on the slab.  inverse = 0: M1-point column transforms times w_n^((col_base + c) k1);
+ * inverse = 1: the closing inverse column transforms, scaled by 1/M1 (col_base is not used: the twiddle was applied
+ * by the relayout on the other side of the exchange) */
+int toyni_ntt_slab_pass_device(toyni_ntt_ctx* ctx, uint32_t* d_slab, size_t cols_local, size_t col_base, int inverse, void* stream);
+/* W = S1 / parts.  inverse = 0 (after the exchange):  in [parts][rows_local][W] -> out [rows_local][parts][W] = [rows_local][S1];
+ * inverse = 1 (before the exchange): in [rows_local][S1] -> out [parts][rows_local][W], times w_n^-((row0 + r) j').
+ * Out of place (d_in != d_out). */
+int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
+                                   size_t parts, int inverse, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. FRI pairwise fold (net-new on the device; oracle src/math/fri.rs:27-48)
  *    out[i] = (a + b)/2 + (a - b)/2 * beta / x_i,  a = evals[i], b = evals[i + m/2],  i < m/2

@@ -36,6 +36,32 @@ class OracleLocalOps:
         a[:] = ((a.astype(np.uint64) * self.w[e]) % np.uint64(P)).astype(np.int32)
 
 
+    # ---- slab form: numpy restatements of the two device stages (tests only)
+    def slab_pass(self, slab, col_base, inverse):
+        a = slab.numpy()
+        m1, w = a.shape
+        for c in range(w):
+            col = a[:, c].astype(np.uint64)
+            if inverse:
+                a[:, c] = oracle.intt(col).astype(np.int32)
+            else:
+                y = oracle.ntt(col)
+                e = (np.uint64(col_base + c) * np.arange(m1, dtype=np.uint64)) % np.uint64(self.n)
+                a[:, c] = ((y * self.w[e]) % np.uint64(P)).astype(np.int32)
+
+    def relayout(self, src, dst, rows, row0, parts, inverse):
+        s1 = src.numel() // rows
+        w = s1 // parts
+        if not inverse:
+            dst.copy_(src.view(parts, rows, w).permute(1, 0, 2).reshape(dst.shape))
+            return
+        a = src.view(rows, s1).numpy().astype(np.uint64)
+        e = (np.arange(row0, row0 + rows, dtype=np.uint64)[:, None] * np.arange(s1, dtype=np.uint64)[None, :]) % np.uint64(self.n)
+        e = (np.uint64(self.n) - e) % np.uint64(self.n)
+        tw = torch.from_numpy(((a * self.w[e]) % np.uint64(P)).astype(np.int32))
+        dst.copy_(tw.view(rows, parts, w).permute(1, 0, 2).reshape(dst.shape))
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -78,6 +104,23 @@ def main():
         assert (out.numpy().astype(np.uint64) == want[idx]).all(), f"4-step forward log_n={log_n} rank={rank}"
         back = tdist.fourstep_inverse(out, log_n, ops, rank, world)
         assert torch.equal(back, cols), f"4-step inverse log_n={log_n} rank={rank}"
+
+    # ---- 3. slab form (no local transposes), same single all-to-all
+    for log_n in (13, 14):
+        l1 = tdist.first_pass_log(log_n)
+        if (1 << (log_n - l1)) < 32 * world:
+            continue
+        nn = 1 << log_n
+        x = oracle.splitmix(nn, 2000 + log_n)
+        want = oracle.ntt(x)
+        ops = OracleLocalOps(log_n)
+        slab = torch.from_numpy(x[tdist.slab_input_index(log_n, world, rank).numpy()].astype(np.int32))
+        keep = slab.clone()
+        out = tdist.slab_forward(slab, log_n, ops, rank, world)
+        idx = tdist.slab_output_index(log_n, world, rank).numpy()
+        assert (out.numpy().astype(np.uint64) == want[idx]).all(), f"slab forward log_n={log_n} rank={rank}"
+        back = tdist.slab_inverse(out, log_n, ops, rank, world)
+        assert torch.equal(back, keep), f"slab inverse log_n={log_n} rank={rank}"
         # every output index is owned exactly once
         owned = [None] * world
         dist.all_gather_object(owned, idx.reshape(-1))

@@ -224,6 +224,82 @@ static void test_merkle(size_t n, bool salted) {
     CHECK(std::memcmp(lv.data(), want.data(), 32 * total) == 0, "merkle n=%zu salted=%d", n, (int)salted);
 }
 
+// One transform over G ranks (include/toyni_hip.h 2b), all ranks stepped in this process: slab pass on every rank's
+// column block, the all-to-all as memcpy, relayout, size-S1 row transforms -- and the mirrored inverse.
+static void emu_slab_pass(const NttPlan& plan, bool inverse, uint32_t* slab, uint64_t cols, uint64_t col_base, const uint32_t* ones) {
+    const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
+    bool ok = slab_pass(plan, blob.data(), inverse, slab, cols, col_base, ones, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+        using P = decltype(pass);
+        std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);
+        for (uint64_t v = 0; v < nblocks; ++v) {
+            const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);
+            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, b, tid, lds.data());
+            if constexpr (P::TWO_STEP) {
+                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
+            }
+        }
+    });
+    CHECK(ok, "slab pass rejected: log_n=%d cols=%llu", plan.log_n, (unsigned long long)cols);
+}
+static void emu_relayout(const NttPlan& plan, const uint32_t* in, uint32_t* out, uint64_t rows, uint64_t row0, uint64_t parts, bool inverse) {
+    const uint64_t s1 = (1ull << plan.log_n) >> plan.pass[0].log_m;
+    auto lg = [](uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return (uint32_t)l; };
+    RelayoutArgs a{};
+    a.in = in; a.out = out;
+    a.log_rows = lg(rows); a.log_parts = lg(parts); a.log_w = lg(s1 / parts);
+    a.inverse = inverse; a.row0 = (uint32_t)row0;
+    a.lo = plan.inv.data() + plan.dom_lo_off; a.hi = plan.inv.data() + plan.dom_hi_off; a.lowbits = plan.dom_lowbits;
+    for (uint64_t o = 0; o < rows * s1; ++o) {
+        uint32_t e;
+        const uint64_t src = relayout_src(a, o, e);
+        out[o] = relayout_value(a, in[src], e);
+    }
+}
+static void test_slab(int log_n, uint64_t G) {
+    NttPlan plan, sub;
+    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    const uint64_t n = 1ull << log_n, m1 = 1ull << plan.pass[0].log_m, s1 = n / m1;
+    CHECK(build_plan(log_n - plan.pass[0].log_m, sub), "sub plan");
+    const uint64_t W = s1 / G, R = m1 / G;
+    std::vector<uint64_t> x(n), want(n);
+    orc_fill_splitmix(x.data(), n, 0x51AB0000ull + (uint64_t)log_n * 16 + G);
+    want = x;
+    orc_ntt_canonical(want.data(), n);
+    const uint32_t lb = plan.pass[0].lowbits;  // exactly the size the library allocates: an overrun is an ASan error
+    std::vector<uint32_t> ones((size_t)1 << (lb > (uint32_t)log_n - lb ? lb : (uint32_t)log_n - lb), to_mont_host(1u));
+    // rank g's slab [M1][W]
+    std::vector<std::vector<uint32_t>> slab(G, std::vector<uint32_t>(m1 * W)), recv(G, std::vector<uint32_t>(m1 * W)), rows(G, std::vector<uint32_t>(R * s1));
+    for (uint64_t g = 0; g < G; ++g)
+        for (uint64_t j1 = 0; j1 < m1; ++j1)
+            for (uint64_t c = 0; c < W; ++c) slab[g][j1 * W + c] = (uint32_t)x[j1 * s1 + g * W + c];
+    std::vector<std::vector<uint32_t>> slab0 = slab;
+    for (uint64_t g = 0; g < G; ++g) emu_slab_pass(plan, false, slab[g].data(), W, g * W, ones.data());
+    // all_to_all_single: rank g's send block h (rows k1 in rank h's block, contiguous) -> rank h's recv block g
+    for (uint64_t g = 0; g < G; ++g)
+        for (uint64_t h = 0; h < G; ++h) std::memcpy(&recv[h][g * R * W], &slab[g][h * R * W], R * W * sizeof(uint32_t));
+    std::vector<uint32_t> work(R * s1);
+    for (uint64_t g = 0; g < G; ++g) {
+        emu_relayout(plan, recv[g].data(), rows[g].data(), R, g * R, G, false);
+        emu_transform(sub, false, rows[g].data(), work.data(), rows[g].data(), R);
+        uint64_t bad = 0;
+        for (uint64_t r = 0; r < R; ++r)
+            for (uint64_t k = 0; k < s1; ++k) bad += rows[g][r * s1 + k] != (uint32_t)want[(g * R + r) + m1 * k];
+        CHECK(bad == 0, "slab forward log_n=%d G=%llu rank=%llu: %llu mismatches", log_n, (unsigned long long)G, (unsigned long long)g, (unsigned long long)bad);
+    }
+    // inverse: back to the input slabs
+    std::vector<std::vector<uint32_t>> send(G, std::vector<uint32_t>(R * s1));
+    for (uint64_t g = 0; g < G; ++g) {
+        emu_transform(sub, true, rows[g].data(), work.data(), rows[g].data(), R);
+        emu_relayout(plan, rows[g].data(), send[g].data(), R, g * R, G, true);
+    }
+    for (uint64_t g = 0; g < G; ++g)
+        for (uint64_t h = 0; h < G; ++h) std::memcpy(&slab[h][g * R * W], &send[g][h * R * W], R * W * sizeof(uint32_t));
+    for (uint64_t g = 0; g < G; ++g) {
+        emu_slab_pass(plan, true, slab[g].data(), W, g * W, ones.data());
+        CHECK(slab[g] == slab0[g], "slab inverse log_n=%d G=%llu rank=%llu", log_n, (unsigned long long)G, (unsigned long long)g);
+    }
+}
+
 int main(int argc, char** argv) {
     int max_log = argc > 1 ? std::atoi(argv[1]) : 16;
     test_field();
@@ -237,12 +313,28 @@ int main(int argc, char** argv) {
         std::fflush(stdout);
     }
     for (int i = 2; i < argc; ++i) {                // extra sizes "LOG" or "LOGxBATCH" (2-pass 2^20, 3-pass 2^21.., wide tiles)
-        int log_n = std::atoi(argv[i]);
         const char* xb = std::strchr(argv[i], 'x');
+        if (argv[i][0] == 's') {                    // "sLOGxG": one transform over G emulated ranks
+            test_slab(std::atoi(argv[i] + 1), xb ? (uint64_t)std::atoll(xb + 1) : 2);
+            std::printf("slab %s failures=%d\n", argv[i], failures);
+            std::fflush(stdout);
+            continue;
+        }
+        int log_n = std::atoi(argv[i]);
         test_ntt(log_n, xb ? (uint64_t)std::atoll(xb + 1) : 1, 0);
         if (!xb) test_coset(log_n, 1, 1234567891u);
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
+    }
+    for (int log_n : {13, 14, 16}) {
+        if (log_n > max_log) continue;
+        for (uint64_t G : {1, 2, 4}) {
+            NttPlan probe;
+            build_plan(log_n, probe);
+            if (((1ull << log_n) >> probe.pass[0].log_m) / G < 32) continue;
+            test_slab(log_n, G);
+        }
+        std::printf("slab log_n=%d failures=%d\n", log_n, failures);
     }
     for (int layer = 0; layer < 6; ++layer) test_fold(10, layer, 7);
     test_fold(13, 0, 7);

@@ -10,7 +10,9 @@ def test_kernel_bodies_match_oracle_on_cpu():
     exe = entry.build_emu()
     # sizes 2^0..2^14 (1- and 2-pass), plus 2^20 (the 1024 x 1024 headline split; 8-wide tiles at batch 1, 16-wide at
     # batch 4, 32-wide at batch 16 -- the streaming configuration) and 2^21 (3-pass)
-    res = subprocess.run([exe, "14", "20", "20x4", "20x16", "21"], capture_output=True, text=True, timeout=900)
+    # sLOGxG: one transform split over G emulated ranks (slab pass / relayout / row transforms, include/toyni_hip.h 2b):
+    # 2^20 over 2 (1024-point first pass, 8-wide tiles) and 2^21 over 4 (3-pass plan); 2^13, 2^14 run by default
+    res = subprocess.run([exe, "14", "20", "20x4", "20x16", "21", "s20x2", "s21x4"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout
 
@@ -19,6 +21,6 @@ def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
     # every tile / LDS / table index of every pass shape stays in bounds (global buffers are exactly n * batch words,
     # the LDS array exactly LDS_WORDS + 1): 2^0..2^11 with ragged batches, 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
     exe = entry.build_emu_sanitized()
-    res = subprocess.run([exe, "11", "20", "21"], capture_output=True, text=True, timeout=900)
+    res = subprocess.run([exe, "11", "20", "21", "s16x2", "s21x8"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "ALL OK" in res.stdout

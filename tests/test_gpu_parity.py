@@ -487,6 +487,84 @@ def test_fourstep_2_27_equals_single_device_transform(ta):
     assert (got.T.reshape(-1) == direct).all()
 
 
+# slab form (include/toyni_hip.h 2b): `world` ranks stepped one after the other on the one GPU, the all-to-all done by
+# hand -- exercises col_base / row0 / parts of the device stages exactly as a real multi-rank run sets them
+@pytest.mark.parametrize("log_n,world", [(13, 1), (14, 4), (16, 2), (20, 1), (20, 8), (21, 4), (24, 8)])
+def test_slab_ranks_on_one_gpu_match_oracle(ta, log_n, world):
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    x = oracle.splitmix(n, 700 + log_n)
+    want = oracle.ntt(x)
+    ops = tdist.HipLocalOps(log_n, dev)
+    l1, ls = tdist.slab_split(log_n, world)
+    m1, s1 = 1 << l1, 1 << ls
+    w, r = s1 // world, m1 // world
+    slabs = [torch.from_numpy(x[tdist.slab_input_index(log_n, world, g).numpy()].astype(np.int32)).to(dev) for g in range(world)]
+    keep = [t.clone() for t in slabs]
+    for g in range(world):
+        ops.slab_pass(slabs[g], g * w, False)
+    rows = []
+    for h in range(world):                                      # rank h receives row block h of every rank's slab
+        recv = torch.stack([slabs[g].view(world, r, w)[h] for g in range(world)]).contiguous()
+        out = torch.empty((r, s1), dtype=torch.int32, device=dev)
+        ops.relayout(recv, out, r, h * r, world, False)
+        ops.ntt_rows(out, False)
+        rows.append(out)
+    torch.cuda.synchronize()
+    for h in range(world):
+        idx = tdist.slab_output_index(log_n, world, h).numpy()
+        assert (rows[h].cpu().numpy().view(np.uint32).astype(np.uint64) == want[idx]).all(), f"forward rank {h}"
+    sends = []
+    for h in range(world):
+        ops.ntt_rows(rows[h], True)
+        send = torch.empty((world, r, w), dtype=torch.int32, device=dev)
+        ops.relayout(rows[h], send, r, h * r, world, True)
+        sends.append(send)
+    for g in range(world):
+        slab = torch.stack([sends[h][g] for h in range(world)]).reshape(m1, w).contiguous()
+        ops.slab_pass(slab, g * w, True)
+        torch.cuda.synchronize()
+        assert torch.equal(slab, keep[g]), f"inverse rank {g}"
+
+
+def test_slab_2_27_equals_single_device_transform(ta):
+    # configs[4] at the field's limit, one rank, through the shipped driver (exchange = copy): M1 = 512, S1 = 2^18
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    log_n = 27
+    n = 1 << log_n
+    x32 = oracle.splitmix(n, 2728).astype(np.uint32)
+    direct = dev_transform(ta, x32, n, 1, False)
+    ops = tdist.HipLocalOps(log_n, dev)
+    l1, ls = tdist.slab_split(log_n, 1)
+    slab = torch.from_numpy(x32.view(np.int32).reshape(1 << l1, 1 << ls)).to(dev)
+    out = tdist.slab_forward(slab, log_n, ops)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)                     # [k1][k'] -> X[k1 + M1 k']
+    assert (got.T.reshape(-1) == direct).all()
+    back = tdist.slab_inverse(out, log_n, ops)
+    torch.cuda.synchronize()
+    assert (back.cpu().numpy().view(np.uint32).reshape(-1) == x32).all()
+
+
+def test_slab_entry_points_reject_bad_shapes(ta):
+    from toyni_amd._lib import lib
+    small = ta.ntt.get_or_create_ctx(1024)
+    assert lib.toyni_ntt_ctx_first_pass_points(small.handle) == 0
+    big = ta.ntt.get_or_create_ctx(1 << 16)
+    assert lib.toyni_ntt_ctx_first_pass_points(big.handle) == 256
+    buf = ta.GpuBuffer(1 << 16)
+    assert lib.toyni_ntt_slab_pass_device(small.handle, buf.ptr, 32, 0, 0, None) == 10001      # single-pass plan
+    assert lib.toyni_ntt_slab_pass_device(big.handle, buf.ptr, 16, 0, 0, None) == 10006        # < 32 columns
+    assert lib.toyni_ntt_slab_pass_device(big.handle, buf.ptr, 48, 0, 0, None) == 10006        # not a power of two
+    assert lib.toyni_ntt_slab_pass_device(big.handle, buf.ptr, 128, 192, 0, None) == 10006     # runs past column S1
+    assert lib.toyni_ntt_slab_relayout_device(big.handle, buf.ptr, buf.ptr, 256, 0, 1, 0, None) == 10006   # in place
+    buf.free()
+
+
 # ---------------------------------------------------------------- Ext-valued fold (src/math/fri.rs:7-25)
 @pytest.mark.parametrize("m", [2, 8, 1024, 1 << 15])
 def test_fold_ext_vs_oracle(ta, m):

@@ -74,6 +74,9 @@ SIGNATURES = {
     "toyni_ntt_ext_host": (c_int, [c_void_p, c_void_p, c_u64, c_int]),
     "toyni_ntt_ext_device": (c_int, [c_void_p, c_void_p, c_u32, c_int, c_void_p]),
     "toyni_fourstep_twiddle_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
+    "toyni_ntt_ctx_first_pass_points": (c_size, [c_void_p]),
+    "toyni_ntt_slab_pass_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_int, c_void_p]),
+    "toyni_ntt_slab_relayout_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
     # section 3
     "toyni_fri_fold_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p]),
     "toyni_fri_fold_layers_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),

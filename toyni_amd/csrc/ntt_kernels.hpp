@@ -58,6 +58,9 @@ struct PassArgs {
     uint32_t cs_lowbits;
     uint32_t cs_mode;
     uint32_t cs_g;
+    // KIND_COL on a column SLAB of the [M_1][S] view (one rank of a multi-GPU transform, toyni_ntt_slab_pass_device):
+    // local column c is global column col_base + c -- only the inter-pass twiddle sees the difference.
+    uint32_t col_base;
 };
 
 // Diagnostic builds only (-DTOYNI_ABLATE=1|2|3, never the shipped library): bit 0 replaces tile loads by register
@@ -163,6 +166,7 @@ struct Pass {
             const uint64_t base = (prefix << (a.log_S + LM)) + t.col0;
             t.in = a.in + base;
             t.out = a.out + base;
+            t.col0 += a.col_base;  // from here on col0 only feeds twiddle exponents
         } else if (KIND == KIND_ROW_T) {
             const uint32_t mid = bid & ((1u << a.log_mid) - 1);
             const uint32_t k1_tiles_log = a.log_M1 - LC;
@@ -446,6 +450,41 @@ struct Pass {
 // ---- u64 <-> u32 edge of the reference-shaped entry points (src/ntt.rs:233: &mut [BabyBear] as *mut u64) ----
 // narrow also reduces mod p, so a non-canonical u64 behaves like BabyBear::new (src/babybear.rs:26-30)
 TOYNI_HD uint32_t narrow_u64(uint64_t v) { return (uint32_t)(v % BB_P); }
+
+// ---- re-layout around the one exchange of a multi-device transform (toyni_ntt_slab_relayout_device) ----
+// rows = this rank's k_1 block, parts = ranks, W = S_1 / parts columns per piece.
+//   forward (after the exchange) : in [parts][rows][W] -> out [rows][parts][W]        (pieces -> contiguous rows)
+//   inverse (before the exchange): in [rows][parts][W] -> out [parts][rows][W], times w_n^-(k1 j'), k1 = row0 + r,
+//                                  j' = g W + w -- the twiddle between the row transforms and the column transforms
+struct RelayoutArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t log_rows, log_parts, log_w;
+    uint32_t inverse, row0;
+    const uint32_t* lo;   // w_n^-x two-level table (inverse only)
+    const uint32_t* hi;
+    uint32_t lowbits;
+};
+// source index and twiddle exponent of OUTPUT element o (consecutive o within a piece map to consecutive sources)
+TOYNI_HD uint64_t relayout_src(const RelayoutArgs& a, uint64_t o, uint32_t& exponent) {
+    const uint32_t w = (uint32_t)o & ((1u << a.log_w) - 1u);
+    uint32_t r, g;
+    if (!a.inverse) {
+        g = (uint32_t)(o >> a.log_w) & ((1u << a.log_parts) - 1u);
+        r = (uint32_t)(o >> (a.log_w + a.log_parts));
+        exponent = 0u;
+        return ((((uint64_t)g << a.log_rows) + r) << a.log_w) + w;
+    }
+    r = (uint32_t)(o >> a.log_w) & ((1u << a.log_rows) - 1u);
+    g = (uint32_t)(o >> (a.log_w + a.log_rows));
+    exponent = (a.row0 + r) * ((g << a.log_w) + w);  // k1 j' < n <= 2^27
+    return ((((uint64_t)r << a.log_parts) + g) << a.log_w) + w;
+}
+TOYNI_HD uint32_t relayout_value(const RelayoutArgs& a, uint32_t v, uint32_t exponent) {
+    if (!a.inverse) return v;
+    const uint32_t tw = mont_mul(a.hi[exponent >> a.lowbits], a.lo[exponent & ((1u << a.lowbits) - 1u)]);
+    return mont_mul(v, tw);
+}
 
 // ---- FRI pairwise fold (src/math/fri.rs:27-48), structured-domain form ----
 // Layer points are x_i = x0 * w_m^i (prover: src/fibonacci.rs:214,228-231), so

@@ -230,4 +230,42 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
     return true;
 }
 
+// ---- one transform split over several devices (toyni_hip.h, section 2b) --------------------------------
+// View x as [M_1][S_1] (M_1 = the plan's first-pass size): the first pass only couples elements of one column, so a
+// rank that owns a contiguous block of columns runs it alone; what is left after it is, for every k_1, an ordinary
+// size-S_1 transform over j' (src/ntt.rs:11-51 applied recursively).
+//   forward : slab[j1][c] = x[j1 S_1 + col_base + c]  ->  w_n^((col_base + c) k1) * sum_j1 slab[j1][c] w_M1^(j1 k1), in place
+//   inverse : the closing column transforms of the mirrored algorithm: sum_k1 slab[k1][c] w_M1^-(j1 k1) / M_1, no
+//             twiddle (it is applied by the relayout before the exchange); `ones` = table of Montgomery ones,
+//             max(2^lowbits, n >> lowbits) words, standing in for the inter-pass twiddle table.
+// launch(PassType{}, args, nblocks).
+template <class Launch>
+inline bool slab_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, uint32_t* slab, uint64_t cols_local,
+                      uint64_t col_base, const uint32_t* ones, Launch&& launch) {
+    if (plan.npasses < 2 || cols_local < 32 || (cols_local & (cols_local - 1))) return false;
+    const PassPlan& pp = plan.pass[0];
+    if (col_base + cols_local > (1ull << pp.log_s)) return false;
+    int log_c = 0;
+    while ((1ull << log_c) < cols_local) ++log_c;
+    PassArgs a{};
+    a.in = slab;
+    a.out = slab;
+    a.stage_tw = tables + pp.stage_off;
+    a.tw_lowbits = pp.lowbits;
+    a.log_S = (uint32_t)log_c;
+    if (!inverse) {
+        a.tw_lo = tables + pp.lo_off;
+        a.tw_hi = tables + pp.hi_off;
+        a.col_base = (uint32_t)col_base;
+    } else {
+        a.tw_lo = ones;
+        a.tw_hi = ones;
+        a.scale = to_mont_host(bb_inv_host((uint32_t)(1u << pp.log_m)));
+    }
+    return dispatch_pass(KIND_COL, pp.log_m, log_c - 5, [&](auto pass) {
+        using P = decltype(pass);
+        launch(pass, a, cols_local / P::C);
+    });
+}
+
 }  // namespace toyni

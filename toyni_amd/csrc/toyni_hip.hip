@@ -139,6 +139,24 @@ __global__ void __launch_bounds__(256) fourstep_twiddle_kernel(uint32_t* __restr
     }
 }
 
+// slab relayout (ntt_kernels.hpp): four consecutive output words per thread, 16-byte accesses on both sides (W >= 32)
+__global__ void __launch_bounds__(256) slab_relayout_kernel(const RelayoutArgs a, uint64_t quads) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        uint32_t e0, e3;
+        const uint64_t src = relayout_src(a, 4 * q, e0);
+        (void)relayout_src(a, 4 * q + 3, e3);
+        const uint4 v = *reinterpret_cast<const uint4*>(a.in + src);
+        const uint32_t de = (e3 - e0) / 3u;  // the exponent is linear in w: k1 per step
+        uint4 r;
+        r.x = relayout_value(a, v.x, e0);
+        r.y = relayout_value(a, v.y, e0 + de);
+        r.z = relayout_value(a, v.z, e0 + 2u * de);
+        r.w = relayout_value(a, v.w, e3);
+        *reinterpret_cast<uint4*>(a.out + 4 * q) = r;
+    }
+}
+
 // FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows
 __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
     const uint64_t half = f.half;
@@ -352,6 +370,7 @@ struct toyni_ntt_ctx {
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
+    uint32_t* d_ones = nullptr;      // Montgomery ones: the twiddle-free closing pass of a multi-device inverse (slab_pass)
     std::mutex mu;
 };
 
@@ -549,6 +568,7 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         (void)hipFree(c->d_data32);
         (void)hipFree(c->d_stage64);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
+        (void)hipFree(c->d_ones);
     }
     delete c;
     return TOYNI_OK;
@@ -704,6 +724,61 @@ int toyni_fourstep_twiddle_device(toyni_ntt_ctx* c, uint32_t* d_data, size_t row
     const uint64_t total = (uint64_t)rows * row_len;
     hipLaunchKernelGGL(fourstep_twiddle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_data, total, (uint32_t)ilog2(row_len),
                        (uint32_t)row0, t + c->plan.dom_lo_off, t + c->plan.dom_hi_off, c->plan.dom_lowbits);
+    return (int)hipGetLastError();
+}
+
+// ---- one transform over several devices: the local stages either side of the caller's all-to-all ----
+size_t toyni_ntt_ctx_first_pass_points(const toyni_ntt_ctx* c) {
+    return (c && c->plan.npasses >= 2) ? (size_t)1 << c->plan.pass[0].log_m : 0;
+}
+
+int toyni_ntt_slab_pass_device(toyni_ntt_ctx* c, uint32_t* d_slab, size_t cols_local, size_t col_base, int inverse, void* stream) {
+    if (!c || !d_slab) return TOYNI_E_NULL;
+    if (c->plan.npasses < 2) return TOYNI_E_INVALID_SIZE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    if (inverse && !c->d_ones) {
+        const uint32_t lowbits = c->plan.pass[0].lowbits;
+        const size_t words = (size_t)1 << (lowbits > c->plan.log_n - lowbits ? lowbits : c->plan.log_n - lowbits);
+        std::vector<uint32_t> ones(words, to_mont_host(1u));
+        HIPCHK(hipMalloc((void**)&c->d_ones, words * sizeof(uint32_t)));
+        hipError_t e = hipMemcpy(c->d_ones, ones.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(c->d_ones); c->d_ones = nullptr; return (int)e; }
+    }
+    hipError_t err = hipSuccess;
+    const bool ok = slab_pass(c->plan, inverse ? c->d_inv : c->d_fwd, inverse != 0, d_slab, cols_local, col_base, c->d_ones,
+                              [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+                                  using P = decltype(pass);
+                                  launch_pass<P>(persistent_grid<P>(c, nblocks), (hipStream_t)stream, a, (uint32_t)nblocks);
+                                  err = hipGetLastError();
+                              });
+    if (!ok) return TOYNI_E_RANGE;
+    return (int)err;
+}
+
+int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0, size_t parts,
+                                   int inverse, void* stream) {
+    if (!c || !d_in || !d_out) return TOYNI_E_NULL;
+    if (d_in == d_out) return TOYNI_E_RANGE;
+    const size_t m1 = toyni_ntt_ctx_first_pass_points(c);
+    if (!m1) return TOYNI_E_INVALID_SIZE;
+    const size_t s1 = (size_t)c->n / m1;
+    if (!is_pow2(rows_local) || !is_pow2(parts) || parts > s1 || s1 / parts < 32 || row0 + rows_local > m1) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    RelayoutArgs a{};
+    a.in = d_in;
+    a.out = d_out;
+    a.log_rows = (uint32_t)ilog2(rows_local);
+    a.log_parts = (uint32_t)ilog2(parts);
+    a.log_w = (uint32_t)ilog2(s1 / parts);
+    a.inverse = inverse ? 1u : 0u;
+    a.row0 = (uint32_t)row0;
+    a.lo = c->d_inv + c->plan.dom_lo_off;
+    a.hi = c->d_inv + c->plan.dom_hi_off;
+    a.lowbits = c->plan.dom_lowbits;
+    const uint64_t quads = ((uint64_t)rows_local * s1) / 4;
+    hipLaunchKernelGGL(slab_relayout_kernel, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, a, quads);
     return (int)hipGetLastError();
 }
 

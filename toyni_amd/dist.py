@@ -12,6 +12,14 @@
    transforms finish.  Output layout: rank g holds X[k1 + n1 k2] for k1 in its chunk as a [n1/G, n2] array
    (`fourstep_output_index` gives the natural index).  `fourstep_inverse` is the exact mirror.
 
+3. The same transform WITHOUT local transposes (`slab_forward` / `slab_inverse`, include/toyni_hip.h section 2b): split
+   n = M1 * S1 where M1 is the first-pass size of the single-device plan.  That pass only couples elements of one
+   column of the [M1][S1] view, so each rank runs it on its own column slab with the ordinary strided pass kernel
+   (twiddle fused, column offset = its slab's position); the all-to-all then moves CONTIGUOUS row blocks, one relayout
+   makes rows contiguous, and the remaining work is a plain batch of size-S1 transforms.  4 HBM sweeps per direction
+   at n = 2^27 against 8 for form 2 (which pays for two transposes, a separate twiddle pass and pack / unpack copies).
+   Same input / output layouts as form 2 with (n1, n2) = (M1, S1).
+
 The reference has no counterpart (single device, no collectives: cuda/ntt_kernel.cu:246-248); values are pinned by
 the single-device transform / the oracle on the gathered result.
 
@@ -70,6 +78,41 @@ def fourstep_input_index(log_n: int, world: int, rank: int) -> torch.Tensor:
     return j1 * n2 + j2
 
 
+def first_pass_log(log_n: int) -> int:
+    """log2 M1 of the single-device plan (toyni_amd/csrc/ntt_plan.hpp split_passes); 0 when the transform is single-pass."""
+    if log_n <= 10:
+        return 0
+    return (log_n + 1) // 2 if log_n <= 20 else (log_n + 2) // 3
+
+
+def slab_split(log_n: int, world: int) -> Tuple[int, int]:
+    """(log M1, log S1) of the slab form; every rank needs >= 32 columns and >= 1 row."""
+    l1 = first_pass_log(log_n)
+    assert l1 > 0, "transform too small to split (n <= 1024 is a single pass)"
+    ls = log_n - l1
+    assert world & (world - 1) == 0, "world size must be a power of two"
+    assert (1 << ls) >= 32 * world and (1 << l1) >= world, "transform too small to split over this many ranks"
+    return l1, ls
+
+
+def slab_input_index(log_n: int, world: int, rank: int) -> torch.Tensor:
+    """Natural index j = j1*S1 + j' of every element of rank's [M1, S1/G] input slab (int64)."""
+    l1, ls = slab_split(log_n, world)
+    w = (1 << ls) // world
+    j1 = torch.arange(1 << l1, dtype=torch.int64).unsqueeze(1)
+    jc = torch.arange(rank * w, (rank + 1) * w, dtype=torch.int64).unsqueeze(0)
+    return j1 * (1 << ls) + jc
+
+
+def slab_output_index(log_n: int, world: int, rank: int) -> torch.Tensor:
+    """Natural index k = k1 + M1*k' of every element of rank's [M1/G, S1] output block (int64)."""
+    l1, ls = slab_split(log_n, world)
+    r = (1 << l1) // world
+    k1 = torch.arange(rank * r, (rank + 1) * r, dtype=torch.int64).unsqueeze(1)
+    kp = torch.arange(1 << ls, dtype=torch.int64).unsqueeze(0)
+    return k1 + (1 << l1) * kp
+
+
 class HipLocalOps:
     """Local stages on the GPU through the C ABI (contexts cached per size)."""
 
@@ -96,6 +139,23 @@ class HipLocalOps:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(lib.toyni_fourstep_twiddle_device(self.big.handle, t.data_ptr(), t.shape[0], t.shape[1], row0, int(inverse), stream or None),
               "4-step twiddle failed")
+
+
+    # ---- slab form (include/toyni_hip.h section 2b)
+    def slab_pass(self, slab: torch.Tensor, col_base: int, inverse: bool) -> None:
+        from ._lib import check, lib
+        assert slab.is_contiguous() and slab.dtype == torch.int32 and slab.dim() == 2
+        assert slab.shape[0] == lib.toyni_ntt_ctx_first_pass_points(self.big.handle), "slab rows must be the plan's first-pass size"
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.toyni_ntt_slab_pass_device(self.big.handle, slab.data_ptr(), slab.shape[1], col_base, int(inverse), stream or None),
+              "slab pass failed")
+
+    def relayout(self, src: torch.Tensor, dst: torch.Tensor, rows: int, row0: int, parts: int, inverse: bool) -> None:
+        from ._lib import check, lib
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.int32 and src.numel() == dst.numel()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.toyni_ntt_slab_relayout_device(self.big.handle, src.data_ptr(), dst.data_ptr(), rows, row0, parts, int(inverse), stream or None),
+              "slab relayout failed")
 
 
 def _exchange(send: torch.Tensor, group=None) -> torch.Tensor:
@@ -138,3 +198,31 @@ def fourstep_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: 
     ops.twiddle(t, rank * c, True)                 # * w_n^-(j2 k1)
     ops.ntt_rows(t, True)                          # inverse n1-point over k1, scaled by n1^-1
     return t.t().contiguous()
+
+
+def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+    """slab: [M1, S1/G] int32, element (j1, c) = x[j1*S1 + rank*S1/G + c]; OVERWRITTEN.  Returns [M1/G, S1] (slab_output_index)."""
+    l1, ls = slab_split(log_n, world)
+    m1, s1 = 1 << l1, 1 << ls
+    w, r = s1 // world, m1 // world
+    assert slab.shape == (m1, w) and slab.is_contiguous()
+    ops.slab_pass(slab, rank * w, False)           # M1-point column transforms * w_n^(j' k1), in place, no transpose
+    recv = _exchange(slab.view(world, r, w), group)  # row block h (k1 in rank h's chunk) is contiguous: no packing
+    rows = torch.empty((r, s1), dtype=slab.dtype, device=slab.device)
+    ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
+    ops.ntt_rows(rows, False)                      # what is left: size-S1 transforms over j'
+    return rows
+
+
+def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+    """Mirror of slab_forward: [M1/G, S1] block of X (OVERWRITTEN) -> [M1, S1/G] slab of x."""
+    l1, ls = slab_split(log_n, world)
+    m1, s1 = 1 << l1, 1 << ls
+    w, r = s1 // world, m1 // world
+    assert rows.shape == (r, s1) and rows.is_contiguous()
+    ops.ntt_rows(rows, True)                       # inverse size-S1 over k', scaled by 1/S1
+    send = torch.empty((world, r, w), dtype=rows.dtype, device=rows.device)
+    ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
+    slab = _exchange(send, group).view(m1, w)      # block g = k1 in rank g's chunk: the [M1][w] slab
+    ops.slab_pass(slab, rank * w, True)            # inverse M1-point column transforms, scaled by 1/M1
+    return slab
