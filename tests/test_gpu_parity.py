@@ -565,6 +565,29 @@ def test_slab_entry_points_reject_bad_shapes(ta):
     buf.free()
 
 
+def test_in_workload_launch_timing(ta):
+    # toyni_ntt_ctx_timing: every pass launch between enable and read is bracketed by events; results are untouched
+    n, batch = 1 << 16, 8
+    x = oracle.splitmix(n * batch, 4242).astype(np.uint32)
+    ctx = ta.NttContext(n)
+    buf = DevBuf(ta, x.nbytes)
+    buf.upload(x)
+    ctx.timing(True)
+    ctx.run_device(buf.ptr, buf.ptr, batch, False)
+    ctx.run_device(buf.ptr, buf.ptr, batch, True)
+    ctx.run_device(buf.ptr, buf.ptr, batch, False)
+    t = ctx.read_timing()
+    ctx.timing(False)
+    assert t["launches"] == {"forward": [2, 2], "inverse": [1, 1]}
+    assert all(v is not None and 0.0 < v < 50.0 for v in t["forward"] + t["inverse"])
+    ctx.run_device(buf.ptr, buf.ptr, batch, True)                      # not recorded any more
+    ctx.synchronize()
+    assert ctx.read_timing()["launches"] == {"forward": [0, 0], "inverse": [0, 0]}
+    assert (buf.download(np.uint32, n * batch) == x).all()
+    buf.free()
+    ctx.destroy()
+
+
 # ---------------------------------------------------------------- Ext-valued fold (src/math/fri.rs:7-25)
 @pytest.mark.parametrize("m", [2, 8, 1024, 1 << 15])
 def test_fold_ext_vs_oracle(ta, m):

@@ -370,6 +370,9 @@ struct toyni_ntt_ctx {
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
+    struct TimingRec { hipEvent_t e0, e1; int dir, pass; };
+    bool timing = false;             // toyni_ntt_ctx_timing: bracket every pass launch with events
+    std::vector<TimingRec> timing_recs;
     uint32_t* d_ones = nullptr;      // Montgomery ones: the twiddle-free closing pass of a multi-device inverse (slab_pass)
     std::mutex mu;
 };
@@ -466,12 +469,24 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
+        int pass_index = 0;
         bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n, c->d_work, d_out + b0 * n, nb,
                                 [&](auto pass, const PassArgs& a, uint64_t nblocks) {
                                     using P = decltype(pass);
+                                    const int p = pass_index++;
                                     if (err != hipSuccess) return;
+                                    toyni_ntt_ctx::TimingRec rec{nullptr, nullptr, inverse ? 1 : 0, p};
+                                    if (c->timing) {
+                                        if ((err = hipEventCreate(&rec.e0)) != hipSuccess) return;
+                                        if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
+                                        (void)hipEventRecord(rec.e0, s);
+                                    }
                                     launch_pass<P>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
                                     err = hipGetLastError();
+                                    if (c->timing) {
+                                        (void)hipEventRecord(rec.e1, s);
+                                        c->timing_recs.push_back(rec);
+                                    }
                                 }, cs);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
@@ -569,6 +584,7 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         (void)hipFree(c->d_stage64);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
         (void)hipFree(c->d_ones);
+        for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     }
     delete c;
     return TOYNI_OK;
@@ -577,6 +593,37 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
 uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
 int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
+
+int toyni_ntt_ctx_timing(toyni_ntt_ctx* c, int enable) {
+    if (!c) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    if (enable) {
+        for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        c->timing_recs.clear();
+    }
+    c->timing = enable != 0;
+    return TOYNI_OK;
+}
+
+int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* c, float* ms_sum, uint32_t* launches) {
+    if (!c || !ms_sum || !launches) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    for (int i = 0; i < 2 * MAX_PASSES; ++i) { ms_sum[i] = 0.f; launches[i] = 0u; }
+    hipError_t err = hipSuccess;
+    for (auto& r : c->timing_recs) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (e == hipSuccess && r.pass < MAX_PASSES) { ms_sum[r.dir * MAX_PASSES + r.pass] += ms; launches[r.dir * MAX_PASSES + r.pass] += 1u; }
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    c->timing_recs.clear();
+    return (int)err;
+}
 
 int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* c, size_t chunk_elems) {
     if (!c) return TOYNI_E_NULL;

@@ -121,6 +121,21 @@ class NttContext:
         check(lib.toyni_ntt_profile_passes(self.handle, d_data, batch, int(inverse), reps, out, stream or None), "profile failed")
         return [out[i] for i in range(self.passes)]
 
+    def timing(self, enable: bool) -> None:
+        """Bracket every pass launch of this context with HIP events on its launch stream (see read_timing)."""
+        check(lib.toyni_ntt_ctx_timing(self.handle, int(enable)), "timing switch failed")
+
+    def read_timing(self):
+        """{'forward': [avg ms per launch of pass 0, ...], 'inverse': [...], 'launches': {...}} for the launches since timing(True)."""
+        ms = (ctypes.c_float * 6)()
+        cnt = (ctypes.c_uint32 * 6)()
+        check(lib.toyni_ntt_ctx_timing_read(self.handle, ms, cnt), "timing read failed")
+        out = {"launches": {}}
+        for d, name in enumerate(("forward", "inverse")):
+            out[name] = [ms[3 * d + p] / cnt[3 * d + p] if cnt[3 * d + p] else None for p in range(self.passes)]
+            out["launches"][name] = [int(cnt[3 * d + p]) for p in range(self.passes)]
+        return out
+
     def synchronize(self, stream: int = 0) -> None:
         check(lib.toyni_stream_synchronize(self.handle, stream or None), "stream synchronize failed")
 
