@@ -69,6 +69,16 @@ def intt_gpu(values) -> None:
     get_or_create_ctx(n).run_host(v, inverse=True)
 
 
+def ntt_host_multi_gpu(values: np.ndarray, n: int, devices, inverse: bool = False) -> None:
+    """values: batch * n u64 elements in place; the batch is sharded contiguously over `devices` (ordinals; listing a
+    device twice gives two lanes on it, whose H2D / D2H copies overlap on the full-duplex PCIe link).  One host thread
+    and one context per entry, no collective (toyni_ntt_host_multi_gpu)."""
+    v = _as_u64(values)
+    assert v.size % n == 0
+    devs = (ctypes.c_int * len(devices))(*devices)
+    check(lib.toyni_ntt_host_multi_gpu(devs, len(devices), n, v.ctypes.data, v.size // n, int(inverse)), "multi-GPU host NTT failed")
+
+
 class NttContext:
     """Persistent per-n context: twiddles + reusable device buffers (NttCtx, cuda/ntt_kernel.cu:202-209)."""
 
