@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--microbench", action="store_true", help="also print integer-multiply issue rates (stderr)")
+    ap.add_argument("--chunks", type=int, default=1, help="slab workload: issue the exchange in this many asynchronous pieces")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the pass launches of the timed region with HIP events (A/B check of their cost)")
     ap.add_argument("--workload", choices=["batch", "fourstep", "slab"], default="batch",
@@ -104,8 +105,8 @@ def bench_fourstep(args, dev, rank, world, distributed):
 
     def step():
         if slab:                     # both directions overwrite their input; the inverse's result feeds the next step
-            out = tdist.slab_forward(state["slab"], log_n, ops, rank, world)
-            state["slab"] = tdist.slab_inverse(out, log_n, ops, rank, world)
+            out = tdist.slab_forward(state["slab"], log_n, ops, rank, world, chunks=args.chunks)
+            state["slab"] = tdist.slab_inverse(out, log_n, ops, rank, world, chunks=args.chunks)
             return state["slab"]
         out = tdist.fourstep_forward(cols, log_n, ops, rank, world)
         return tdist.fourstep_inverse(out, log_n, ops, rank, world)
@@ -147,13 +148,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # TOYNI_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share devices round-robin,
+    # collectives run on CPU tensors): it exercises this file's world > 1 control flow, not RCCL.  Default: nccl (= RCCL).
+    backend = os.environ.get("TOYNI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+    dev = torch.device("cuda", dev_index if distributed else 0)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")   # where collective payloads live
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -216,7 +225,7 @@ def main():
     # forward + inverse leaves the batch unchanged: a free end-to-end sanity check of the timed region
     assert torch.equal(data[: n], check_before), "round trip changed the data"
 
-    el = torch.tensor([wall], dtype=torch.float64, device=dev)
+    el = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
     if distributed:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall_max = float(el.item())

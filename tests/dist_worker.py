@@ -121,6 +121,14 @@ def main():
         assert (out.numpy().astype(np.uint64) == want[idx]).all(), f"slab forward log_n={log_n} rank={rank}"
         back = tdist.slab_inverse(out, log_n, ops, rank, world)
         assert torch.equal(back, keep), f"slab inverse log_n={log_n} rank={rank}"
+        # the same with the exchange issued as asynchronous pieces (batched isend / irecv) overlapped with the row work
+        for chunks in (2, 4):
+            if ((1 << l1) // world) % chunks:
+                continue
+            out = tdist.slab_forward(keep.clone(), log_n, ops, rank, world, chunks=chunks)
+            assert (out.numpy().astype(np.uint64) == want[idx]).all(), f"chunked slab forward log_n={log_n} rank={rank} chunks={chunks}"
+            back = tdist.slab_inverse(out, log_n, ops, rank, world, chunks=chunks)
+            assert torch.equal(back, keep), f"chunked slab inverse log_n={log_n} rank={rank} chunks={chunks}"
         # every output index is owned exactly once
         owned = [None] * world
         dist.all_gather_object(owned, idx.reshape(-1))

@@ -529,6 +529,26 @@ def test_slab_ranks_on_one_gpu_match_oracle(ta, log_n, world):
         assert torch.equal(slab, keep[g]), f"inverse rank {g}"
 
 
+@pytest.mark.parametrize("log_n,chunks", [(16, 1), (20, 4), (22, 8)])
+def test_slab_driver_world1_matches_oracle(ta, log_n, chunks):
+    # the shipped driver end to end (one rank: the exchange is the identity / local block copies), plain and chunked
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    x = oracle.splitmix(n, 900 + log_n)
+    ops = tdist.HipLocalOps(log_n, dev)
+    slab = torch.from_numpy(x[tdist.slab_input_index(log_n, 1, 0).numpy()].astype(np.int32)).to(dev)
+    keep = slab.clone()
+    out = tdist.slab_forward(slab, log_n, ops, chunks=chunks)
+    torch.cuda.synchronize()
+    idx = tdist.slab_output_index(log_n, 1, 0).numpy()
+    assert (out.cpu().numpy().view(np.uint32).astype(np.uint64) == oracle.ntt(x)[idx]).all()
+    back = tdist.slab_inverse(out, log_n, ops, chunks=chunks)
+    torch.cuda.synchronize()
+    assert torch.equal(back, keep)
+
+
 def test_slab_2_27_equals_single_device_transform(ta):
     # configs[4] at the field's limit, one rank, through the shipped driver (exchange = copy): M1 = 512, S1 = 2^18
     import torch

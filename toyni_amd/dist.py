@@ -160,11 +160,10 @@ class HipLocalOps:
 
 def _exchange(send: torch.Tensor, group=None) -> torch.Tensor:
     """The one all-to-all: send[h] goes to rank h; returns recv with recv[g] from rank g."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return send                                # one rank: the exchange is the identity (no copy; callers never reuse `send`)
     recv = torch.empty_like(send)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_to_all_single(recv, send, group=group)
-    else:
-        recv.copy_(send)
+    dist.all_to_all_single(recv, send, group=group)
     return recv
 
 
@@ -200,29 +199,80 @@ def fourstep_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: 
     return t.t().contiguous()
 
 
-def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
-    """slab: [M1, S1/G] int32, element (j1, c) = x[j1*S1 + rank*S1/G + c]; OVERWRITTEN.  Returns [M1/G, S1] (slab_output_index)."""
+def _exchange_blocks_async(send_blocks, recv_blocks, rank: int, world: int, group=None):
+    """Block h of `send_blocks` goes to rank h, block g of `recv_blocks` comes from rank g (contiguous tensors, no
+    packing).  Point-to-point sends / receives issued as one batch (one grouped RCCL call on GPUs) and NOT waited for:
+    returns the work handles.  The local block is a plain copy."""
+    recv_blocks[rank].copy_(send_blocks[rank])
+    if world == 1:
+        return []
+    p2p = []
+    for off in range(1, world):
+        dst, src = (rank + off) % world, (rank - off) % world
+        p2p.append(dist.P2POp(dist.isend, send_blocks[dst], dst, group))
+        p2p.append(dist.P2POp(dist.irecv, recv_blocks[src], src, group))
+    return dist.batch_isend_irecv(p2p)
+
+
+def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1) -> torch.Tensor:
+    """slab: [M1, S1/G] int32, element (j1, c) = x[j1*S1 + rank*S1/G + c]; OVERWRITTEN.  Returns [M1/G, S1] (slab_output_index).
+
+    chunks > 1: the exchange is issued as `chunks` asynchronous pieces (sub-blocks of every destination's row block) and
+    the relayout + row transforms of piece q run while pieces q+1.. are still on the wire."""
     l1, ls = slab_split(log_n, world)
     m1, s1 = 1 << l1, 1 << ls
     w, r = s1 // world, m1 // world
     assert slab.shape == (m1, w) and slab.is_contiguous()
     ops.slab_pass(slab, rank * w, False)           # M1-point column transforms * w_n^(j' k1), in place, no transpose
-    recv = _exchange(slab.view(world, r, w), group)  # row block h (k1 in rank h's chunk) is contiguous: no packing
     rows = torch.empty((r, s1), dtype=slab.dtype, device=slab.device)
-    ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
-    ops.ntt_rows(rows, False)                      # what is left: size-S1 transforms over j'
+    if chunks <= 1:
+        recv = _exchange(slab.view(world, r, w), group)  # row block h (k1 in rank h's chunk) is contiguous: no packing
+        ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
+        ops.ntt_rows(rows, False)                  # what is left: size-S1 transforms over j'
+        return rows
+    assert chunks & (chunks - 1) == 0 and r % chunks == 0, "chunks must be a power of two dividing the rows per rank"
+    rq = r // chunks
+    sv = slab.view(world, chunks, rq, w)           # [h, q] = rows q*rq.. of rank h's block: contiguous
+    pending = []
+    for q in range(chunks):                        # everything is put on the wire first, in consumption order
+        recv_q = torch.empty((world, rq, w), dtype=slab.dtype, device=slab.device)
+        works = _exchange_blocks_async([sv[h, q] for h in range(world)], list(recv_q.unbind(0)), rank, world, group)
+        pending.append((recv_q, works))
+    for q, (recv_q, works) in enumerate(pending):
+        for wk in works:
+            wk.wait()
+        part = rows[q * rq:(q + 1) * rq]
+        ops.relayout(recv_q, part, rq, rank * r + q * rq, world, False)
+        ops.ntt_rows(part, False)
     return rows
 
 
-def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
-    """Mirror of slab_forward: [M1/G, S1] block of X (OVERWRITTEN) -> [M1, S1/G] slab of x."""
+def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1) -> torch.Tensor:
+    """Mirror of slab_forward: [M1/G, S1] block of X (OVERWRITTEN) -> [M1, S1/G] slab of x.  chunks > 1: piece q is on the
+    wire while the row transforms of piece q+1 run."""
     l1, ls = slab_split(log_n, world)
     m1, s1 = 1 << l1, 1 << ls
     w, r = s1 // world, m1 // world
     assert rows.shape == (r, s1) and rows.is_contiguous()
-    ops.ntt_rows(rows, True)                       # inverse size-S1 over k', scaled by 1/S1
-    send = torch.empty((world, r, w), dtype=rows.dtype, device=rows.device)
-    ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
-    slab = _exchange(send, group).view(m1, w)      # block g = k1 in rank g's chunk: the [M1][w] slab
+    if chunks <= 1:
+        ops.ntt_rows(rows, True)                   # inverse size-S1 over k', scaled by 1/S1
+        send = torch.empty((world, r, w), dtype=rows.dtype, device=rows.device)
+        ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
+        slab = _exchange(send, group).view(m1, w)  # block g = k1 in rank g's chunk: the [M1][w] slab
+    else:
+        assert chunks & (chunks - 1) == 0 and r % chunks == 0, "chunks must be a power of two dividing the rows per rank"
+        rq = r // chunks
+        slab = torch.empty((m1, w), dtype=rows.dtype, device=rows.device)
+        sv = slab.view(world, chunks, rq, w)
+        works, keep = [], []
+        for q in range(chunks):
+            part = rows[q * rq:(q + 1) * rq]
+            ops.ntt_rows(part, True)
+            send_q = torch.empty((world, rq, w), dtype=rows.dtype, device=rows.device)
+            ops.relayout(part, send_q, rq, rank * r + q * rq, world, True)
+            works += _exchange_blocks_async(list(send_q.unbind(0)), [sv[g, q] for g in range(world)], rank, world, group)
+            keep.append(send_q)                    # alive until the sends have completed
+        for wk in works:
+            wk.wait()
     ops.slab_pass(slab, rank * w, True)            # inverse M1-point column transforms, scaled by 1/M1
     return slab
