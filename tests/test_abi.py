@@ -69,3 +69,33 @@ def test_host_mirror_asserts_like_reference():
         toyni_amd.fri_fold(np.zeros(3, dtype=np.uint64), np.ones(3, dtype=np.uint64), 1)
     with pytest.raises(NotImplementedError):
         toyni_amd.BabyBearDomain(8).fft([1, 2, 3])   # no CPU path in this package
+
+
+def _c_prototypes():
+    """name -> number of parameters, from include/toyni_hip.h"""
+    src = open(os.path.join(ROOT, "include", "toyni_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if name.startswith(("toyni_", "ntt_", "intt_", "cuda_")):
+            protos[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def test_rust_and_integration_bindings_match_the_header():
+    # No Rust toolchain exists here (SURVEY F6), so at least keep the shipped extern blocks honest: every function the
+    # Rust binding (rust/src/ntt_gpu.rs) and INTEGRATION.md declare must exist in the header with the same arity.
+    protos = _c_prototypes()
+    decl = re.compile(r"\bfn\s+([a-z_][a-z0-9_]*)\s*\(([^)]*)\)\s*(?:->\s*[^;{]+)?;")
+    checked = 0
+    for path in ("rust/src/ntt_gpu.rs", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, path)).read()
+        for name, args in decl.findall(text):
+            if not name.startswith(("toyni_", "ntt_", "intt_", "cuda_")):
+                continue
+            assert name in protos, f"{path}: {name} is not declared in include/toyni_hip.h"
+            arity = 0 if not args.strip() else args.count(",") + 1
+            assert arity == protos[name], f"{path}: {name} takes {arity} arguments, the header says {protos[name]}"
+            checked += 1
+    assert checked >= 15
