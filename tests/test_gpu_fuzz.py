@@ -1,0 +1,88 @@
+"""Randomised differential test of the device entry points against the oracle: sizes, batches, directions, coset
+shifts, in place / out of place and chunking drawn from a seeded generator, so every run checks the same few hundred
+cases -- chosen to wander over the dispatch table's seams (1 / 2 / 3-pass plans, 8 / 16 / 32-wide tiles of the
+1024-point passes, ragged single-pass row tiles, batches that are not multiples of anything).  Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+from test_gpu_parity import DevBuf, ta  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rows(x, n, inverse, shift):
+    rows = x.reshape(-1, n).astype(np.uint64)
+    out = np.empty_like(rows)
+    for b, row in enumerate(rows):
+        if shift == 1:
+            out[b] = oracle.intt(row) if inverse else oracle.ntt(row)
+        else:
+            out[b] = oracle.domain_ifft(row, shift) if inverse else oracle.domain_fft(row, n, shift)
+    return out.reshape(-1)
+
+
+def test_random_shapes_against_oracle(ta):
+    rng = np.random.default_rng(0x70796E69)
+    budget = 1 << 23                      # elements per case (oracle time stays in the tens of milliseconds)
+    cases = 0
+    for _ in range(220):
+        log_n = int(rng.integers(0, 21))
+        n = 1 << log_n
+        max_batch = max(1, min(70, budget >> log_n))
+        batch = int(rng.integers(1, max_batch + 1))
+        inverse = bool(rng.integers(0, 2))
+        shift = 1 if rng.integers(0, 3) else int(rng.integers(2, P))
+        inplace = bool(rng.integers(0, 2))
+        chunk = None if rng.integers(0, 4) else int(n * rng.integers(1, batch + 1))
+        x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+        want = _oracle_rows(x, n, inverse, shift)
+        ctx = ta.ntt.get_or_create_ctx(n)
+        if chunk is not None:
+            ctx.set_chunk(chunk)
+        a = DevBuf(ta, x.nbytes)
+        b = a if inplace else DevBuf(ta, x.nbytes)
+        try:
+            a.upload(x)
+            ctx.run_device(a.ptr, b.ptr, batch, inverse, shift=shift)
+            ctx.synchronize()
+            got = b.download(np.uint32, x.size)
+            if not inplace:
+                assert (a.download(np.uint32, x.size) == x).all(), "out-of-place transform modified its input"
+        finally:
+            a.free()
+            if b is not a:
+                b.free()
+            ctx.set_chunk(0)
+        assert (got.astype(np.uint64) == want).all(), \
+            f"log_n={log_n} batch={batch} inverse={inverse} shift={shift} inplace={inplace} chunk={chunk}"
+        cases += 1
+    assert cases == 220
+
+
+def test_random_folds_against_oracle(ta):
+    rng = np.random.default_rng(0xF01D)
+    for _ in range(60):
+        log_m = int(rng.integers(1, 19))
+        m = 1 << log_m
+        shift = int(rng.integers(1, P))
+        beta = int(rng.integers(0, P))
+        evals = rng.integers(0, P, size=m, dtype=np.uint64)
+        xs = oracle.domain_elements(m, shift)
+        want = oracle.fri_fold(evals, xs, beta)
+        assert (ta.fri_fold(evals, xs, beta) == want).all(), f"explicit points m={m}"
+        # structured points on a context at least as large as the layer (layer k of a larger codeword)
+        log_ctx = int(rng.integers(log_m, 21))
+        ctx = ta.ntt.get_or_create_ctx(1 << log_ctx)
+        e32 = evals.astype(np.uint32)
+        a, o = DevBuf(ta, e32.nbytes), DevBuf(ta, max(e32.nbytes // 2, 4))
+        try:
+            a.upload(e32)
+            ta.fri_fold_device(ctx, a.ptr, o.ptr, m, beta, shift)
+            ctx.synchronize()
+            got = o.download(np.uint32, m // 2)
+        finally:
+            a.free()
+            o.free()
+        assert (got.astype(np.uint64) == want).all(), f"structured points m={m} ctx=2^{log_ctx} shift={shift}"
