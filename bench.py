@@ -367,6 +367,32 @@ def main():
                                    "passes_per_transform": c24.passes, "note": "same step as `value` at n = 2^24"}
         c24.destroy()
 
+        # ---- low-degree extension of a batch of columns (src/fibonacci.rs:101-103, blowup 32, coset shift 7): zero padding
+        #      implied (toyni_lde_device) vs padded by hand + the ordinary coset transform
+        l_out, l_blow, l_batch = 21, 5, 64
+        c_lde = toyni_amd.NttContext(1 << l_out, device=dev.index)
+        coeffs = torch.randint(0, P, (l_batch, (1 << l_out) >> l_blow), dtype=torch.int32, device=dev)
+        ext = torch.empty((l_batch, 1 << l_out), dtype=torch.int32, device=dev)
+
+        def lde_fused():
+            c_lde.lde_device(coeffs.data_ptr(), ext.data_ptr(), l_batch, l_blow, 7, stream=stream)
+
+        def lde_padded():
+            ext.zero_()
+            ext[:, : coeffs.shape[1]] = coeffs
+            c_lde.run_device(ext.data_ptr(), ext.data_ptr(), l_batch, False, stream=stream, shift=7)
+
+        lde_padded()
+        ref = ext.clone()
+        lde_fused()
+        assert torch.equal(ext, ref), "lde_device differs from pad + coset transform"
+        t_pad, t_lde = time_dev(lde_padded, 10), time_dev(lde_fused, 10)
+        extras["lde_64x_2^16_to_2^21"] = {"ms_pad_then_transform": t_pad * 1e3, "ms_lde_device": t_lde * 1e3,
+                                           "output_elements_per_s": l_batch * (1 << l_out) / t_lde,
+                                           "note": "blowup 32, coset shift 7; first pass reads 1/32 of the rows and skips butterflies with a zero partner"}
+        del coeffs, ext, ref
+        c_lde.destroy()
+
         # ---- prover-shaped sequence (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident: the NTT /
         #      fold work of one proof: interpolate (INTT 2^16), coset LDE (zero-pad + coset FFT 2^21), the two coset INTTs of
         #      src/fibonacci.rs:145,151, and the 17 FRI folds 2^21 -> 2^4 (src/fibonacci.rs:220-245).  Merkle/transcript and

@@ -90,6 +90,13 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* ctx, uint64_t* d_data, size_t batch, int
 int toyni_coset_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream);
 int toyni_coset_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, uint64_t shift, int inverse);
 
+/* Low-degree extension: the forward coset transform of `batch` coefficient vectors of n >> log_blowup words each
+ * (contiguous, stride n >> log_blowup), zero-padded to n -- what the prover does with every column (src/fibonacci.rs:101-103;
+ * BabyBearDomain::fft pads, src/math/domain.rs:107-123).  The padding is implied, not stored: the first pass reads only the
+ * words that exist and skips the butterflies whose partner is a padding zero.  Out of place; d_out holds batch * n words.
+ * Identical results to zero-padding by hand and calling toyni_coset_ntt_device. */
+int toyni_lde_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream);
+
 /* Extension-field transforms, fft_ext / ifft_ext (src/math/domain.rs:129-151): n Ext elements = 4 words each (AoS,
  * #[repr(C)] Ext { c: [BabyBear; 4] }).  The transform is base-linear, so it is the four coordinate transforms -- issued
  * here as ONE batch of 4 behind ONE call (host form: one PCIe round trip; the de-interleave runs on the device).

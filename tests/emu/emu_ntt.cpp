@@ -38,7 +38,8 @@ using namespace toyni;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
-static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1) {
+static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
+                          int lde_log = 0) {
     const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
     std::vector<uint32_t> cblob;
     CosetTables cs;
@@ -50,17 +51,18 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         cs.hi = cblob.data() + hi_off;
     }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
-    bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+    bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
+        constexpr int LZ = decltype(lzc)::value;
         std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);  // exact size: an out-of-range LDS word is an ASan error
         for (uint64_t v = 0; v < nblocks; ++v) {
             const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);  // the persistent loop's virtual index -> tile
-            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, b, tid, lds.data());
+            for (uint32_t tid = 0; tid < P::T; ++tid) P::template phase1<LZ>(a, b, tid, lds.data());
             if constexpr (P::TWO_STEP) {
                 for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
             }
         }
-    }, cs);
+    }, cs, lde_log);
     CHECK(ok, "no pass instantiation for log_n=%d", plan.log_n);
 }
 
@@ -224,6 +226,26 @@ static void test_merkle(size_t n, bool salted) {
     CHECK(std::memcmp(lv.data(), want.data(), 32 * total) == 0, "merkle n=%zu salted=%d", n, (int)salted);
 }
 
+// Low-degree extension: compact input (n >> lde_log words per transform), zero padding implied, coset shift fused
+static void test_lde(int log_n, uint64_t batch, int lde_log, uint32_t shift) {
+    NttPlan plan;
+    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    const uint64_t n = 1ull << log_n, n_in = n >> lde_log;
+    std::vector<uint64_t> c64(n_in * batch);
+    orc_fill_splitmix(c64.data(), c64.size(), 0x1DE0000ull + (uint64_t)log_n * 64 + (uint64_t)lde_log);
+    std::vector<uint32_t> in(n_in * batch), out(n * batch, 0xDEADBEEFu), work(n * batch);  // `in` is EXACTLY the compact size
+    for (size_t i = 0; i < in.size(); ++i) in[i] = (uint32_t)c64[i];
+    emu_transform(plan, false, in.data(), work.data(), out.data(), batch, shift, lde_log);
+    uint64_t bad = 0;
+    std::vector<uint64_t> want(n);
+    for (uint64_t b = 0; b < batch; ++b) {
+        orc_domain_fft(want.data(), n, c64.data() + b * n_in, n_in, shift);
+        for (uint64_t k = 0; k < n; ++k) bad += out[b * n + k] != (uint32_t)want[k];
+    }
+    CHECK(bad == 0, "lde log_n=%d batch=%llu lde_log=%d shift=%u: %llu mismatches", log_n, (unsigned long long)batch, lde_log, shift,
+          (unsigned long long)bad);
+}
+
 // One transform over G ranks (include/toyni_hip.h 2b), all ranks stepped in this process: slab pass on every rank's
 // column block, the all-to-all as memcpy, relayout, size-S1 row transforms -- and the mirrored inverse.
 static void emu_slab_pass(const NttPlan& plan, bool inverse, uint32_t* slab, uint64_t cols, uint64_t col_base, const uint32_t* ones) {
@@ -309,11 +331,22 @@ int main(int argc, char** argv) {
         test_ntt(log_n, log_n <= 10 ? 70 : 3, 0);   // ragged row tiles for the single-pass kinds
         if (log_n == 8) test_ntt(log_n, 1, 1);      // src/ntt.rs:263-287 input
         test_coset(log_n, log_n <= 10 ? 5 : 2, 7);  // COSET_SHIFT = 7, src/fibonacci.rs:16
+        if (log_n >= 11) {                          // every zero fraction the first pass of this plan supports
+            NttPlan probe;
+            build_plan(log_n, probe);
+            for (int z = 1; z <= probe.pass[0].log_m; ++z) test_lde(log_n, z == 1 ? 3 : 1, z, z & 1 ? 7u : 1u);
+        }
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }
     for (int i = 2; i < argc; ++i) {                // extra sizes "LOG" or "LOGxBATCH" (2-pass 2^20, 3-pass 2^21.., wide tiles)
         const char* xb = std::strchr(argv[i], 'x');
+        if (argv[i][0] == 'l') {                    // "lLOGxZ": low-degree extension of 2^(LOG-Z) coefficients to 2^LOG points
+            test_lde(std::atoi(argv[i] + 1), 2, xb ? std::atoi(xb + 1) : 5, 7);
+            std::printf("lde %s failures=%d\n", argv[i], failures);
+            std::fflush(stdout);
+            continue;
+        }
         if (argv[i][0] == 's') {                    // "sLOGxG": one transform over G emulated ranks
             test_slab(std::atoi(argv[i] + 1), xb ? (uint64_t)std::atoll(xb + 1) : 2);
             std::printf("slab %s failures=%d\n", argv[i], failures);
@@ -323,6 +356,7 @@ int main(int argc, char** argv) {
         int log_n = std::atoi(argv[i]);
         test_ntt(log_n, xb ? (uint64_t)std::atoll(xb + 1) : 1, 0);
         if (!xb) test_coset(log_n, 1, 1234567891u);
+        if (!xb) { test_lde(log_n, 1, 5, 7); test_lde(log_n, 1, 2, 7); }   // blowup 32 (COSET_SHIFT 7) and 4
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }

@@ -86,3 +86,28 @@ def test_random_folds_against_oracle(ta):
             a.free()
             o.free()
         assert (got.astype(np.uint64) == want).all(), f"structured points m={m} ctx=2^{log_ctx} shift={shift}"
+
+
+def test_random_low_degree_extensions_against_oracle(ta):
+    rng = np.random.default_rng(0x1DE)
+    for _ in range(80):
+        log_n = int(rng.integers(1, 21))
+        n = 1 << log_n
+        log_blowup = int(rng.integers(0, log_n + 1))
+        n_in = n >> log_blowup
+        batch = int(rng.integers(1, max(2, min(20, (1 << 22) >> log_n) + 1)))
+        shift = 7 if rng.integers(0, 2) else int(rng.integers(1, P))
+        coeffs = rng.integers(0, P, size=n_in * batch, dtype=np.uint32)
+        ctx = ta.ntt.get_or_create_ctx(n)
+        a, o = DevBuf(ta, coeffs.nbytes), DevBuf(ta, 4 * n * batch)
+        try:
+            a.upload(coeffs)
+            ctx.lde_device(a.ptr, o.ptr, batch, log_blowup, shift)
+            ctx.synchronize()
+            got = o.download(np.uint32, n * batch)
+        finally:
+            a.free()
+            o.free()
+        for b in range(batch):
+            want = oracle.domain_fft(coeffs[b * n_in:(b + 1) * n_in].astype(np.uint64), n, shift)
+            assert (got[b * n:(b + 1) * n].astype(np.uint64) == want).all(), f"log_n={log_n} log_blowup={log_blowup} batch={batch} shift={shift} b={b}"

@@ -585,6 +585,45 @@ def test_slab_entry_points_reject_bad_shapes(ta):
     buf.free()
 
 
+# ---------------------------------------------------------------- low-degree extension (src/fibonacci.rs:101-103)
+@pytest.mark.parametrize("log_n,log_blowup,batch,shift", [
+    (11, 5, 3, 7), (12, 1, 2, 7), (14, 3, 5, 1), (16, 5, 4, 7), (16, 8, 2, 7), (18, 2, 3, 7), (20, 5, 2, 7), (20, 1, 1, 7),
+    (20, 4, 16, 7), (21, 5, 2, 7), (21, 7, 1, 1234567), (22, 3, 1, 7),
+    (8, 3, 5, 7), (10, 5, 2, 7), (3, 3, 2, 7), (16, 12, 2, 7), (20, 0, 1, 7)])   # last row: pad-and-transform fallbacks, blowup 1
+def test_lde_matches_padded_transform_and_oracle(ta, log_n, log_blowup, batch, shift):
+    n, n_in = 1 << log_n, (1 << log_n) >> log_blowup
+    coeffs = oracle.splitmix(n_in * batch, 5000 + 64 * log_n + log_blowup).astype(np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, o = DevBuf(ta, coeffs.nbytes), DevBuf(ta, 4 * n * batch)
+    try:
+        a.upload(coeffs)
+        o.upload(np.full(n * batch, 0xDEADBEEF, dtype=np.uint32))      # every output word must be written
+        ctx.lde_device(a.ptr, o.ptr, batch, log_blowup, shift)
+        ctx.synchronize()
+        got = o.download(np.uint32, n * batch)
+        assert (a.download(np.uint32, coeffs.size) == coeffs).all()
+    finally:
+        a.free()
+        o.free()
+    for b in range(batch):
+        want = oracle.domain_fft(coeffs[b * n_in:(b + 1) * n_in].astype(np.uint64), n, shift)
+        assert (got[b * n:(b + 1) * n].astype(np.uint64) == want).all(), f"transform {b}"
+    padded = np.zeros((batch, n), dtype=np.uint32)
+    padded[:, :n_in] = coeffs.reshape(batch, n_in)
+    assert (dev_transform(ta, padded.reshape(-1), n, batch, False, shift=shift) == got).all()
+
+
+def test_lde_rejects_bad_arguments(ta):
+    ctx = ta.ntt.get_or_create_ctx(1 << 12)
+    buf = DevBuf(ta, 4 << 12)
+    lib = ta._lib.lib
+    assert lib.toyni_lde_device(ctx.handle, buf.ptr, buf.ptr, 1, 2, 7, None) == 10006       # in place with a blow-up
+    assert lib.toyni_lde_device(ctx.handle, buf.ptr, buf.ptr, 1, 13, 7, None) == 10006      # blow-up larger than n
+    assert lib.toyni_lde_device(ctx.handle, buf.ptr, buf.ptr, 1, 1, 0, None) == 10006       # shift 0
+    assert lib.toyni_lde_device(ctx.handle, None, buf.ptr, 1, 1, 7, None) == 10002
+    buf.free()
+
+
 def test_in_workload_launch_timing(ta):
     # toyni_ntt_ctx_timing: every pass launch between enable and read is bracketed by events; results are untouched
     n, batch = 1 << 16, 8

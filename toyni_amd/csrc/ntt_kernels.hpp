@@ -61,6 +61,11 @@ struct PassArgs {
     // KIND_COL on a column SLAB of the [M_1][S] view (one rank of a multi-GPU transform, toyni_ntt_slab_pass_device):
     // local column c is global column col_base + c -- only the inter-pass twiddle sees the difference.
     uint32_t col_base;
+    // KIND_COL input addressing: log2 of the distance (words) between two prefix blocks of the INPUT.  Ordinarily
+    // log_S + log2 M (same as the output); smaller for the first pass of a low-degree extension, whose input holds only
+    // the n >> LZ leading (nonzero) words of every transform (toyni_lde_device).  nz_rows = input rows that exist.
+    uint32_t in_prefix_log;
+    uint32_t nz_rows;
 };
 
 // Diagnostic builds only (-DTOYNI_ABLATE=1|2|3, never the shipped library): bit 0 replaces tile loads by register
@@ -164,7 +169,7 @@ struct Pass {
             const uint64_t prefix = (uint64_t)bid >> tiles_log;
             t.col0 = (bid & ((1u << tiles_log) - 1)) << LC;
             const uint64_t base = (prefix << (a.log_S + LM)) + t.col0;
-            t.in = a.in + base;
+            t.in = a.in + ((prefix << a.in_prefix_log) + t.col0);
             t.out = a.out + base;
             t.col0 += a.col_base;  // from here on col0 only feeds twiddle exponents
         } else if (KIND == KIND_ROW_T) {
@@ -296,6 +301,17 @@ struct Pass {
     //              never wait behind the previous tile's HBM stores the way a vmcnt load would);
     //   SHIFT = 0: the same for every thread -> `uni` holds the top stage's 2^(LE-1) twiddles in SGPRs (the lower
     //              stages reuse them at a stride), and the q = 0 butterflies have twiddle 1 (plain subtract).
+    template <int LE, int SHIFT, int S>
+    static TOYNI_HD void stage_twiddles(uint32_t (&w)[1 << (LE - 1)], uint32_t (&nw)[1 << (LE - 1)], const uint32_t* tw1, uint32_t low,
+                                        const uint32_t* uni) {
+        constexpr int t = S + SHIFT;  // butterfly spans 2^(t+1) elements
+#pragma unroll
+        for (int q = 0; q < (1 << S); ++q) {
+            // a lower stage's twiddles are a stride of the top stage's: w_{2^(t+1)}^q = w_{2^LE}^(q << (LE-1-t))
+            w[q] = SHIFT == 0 ? uni[(uint32_t)q << (LE - 1 - S)] : tw1[(1u << t) - (1u << SHIFT) + low + ((uint32_t)q << SHIFT)];
+            nw[q] = BB_P - w[q];
+        }
+    }
     template <int LE, int SHIFT>
     static TOYNI_HD void stages(uint32_t (&x)[1 << LE], const uint32_t* tw1, uint32_t low, const uint32_t* uni) {
 #pragma unroll
@@ -320,6 +336,37 @@ struct Pass {
         }
     }
 
+    // The same for the first pass of a low-degree extension (KIND_COL step 1 only): on entry only registers
+    // i < 2^(LE-LZ) can be nonzero, so in the top LZ stages every butterfly has a zero partner, (u, 0) -> (u, u * w):
+    // one multiply, no add, and the pairs whose inputs are both still zero are skipped.  Stage S as a template
+    // parameter (compile-time recursion), so every register index is a constant whatever the unroller decides.
+    template <int LE, int SHIFT, int LZ, int S>
+    static TOYNI_HD void stages_lz(uint32_t (&x)[1 << LE], const uint32_t* tw1, uint32_t low, const uint32_t* uni) {
+        constexpr int LZS = LZ < LE ? LZ : LE;
+        constexpr int d = 1 << S;
+        uint32_t w[1 << (LE - 1)], nw[1 << (LE - 1)];
+        stage_twiddles<LE, SHIFT, S>(w, nw, tw1, low, uni);
+        if constexpr (S >= LE - LZS) {
+            // live inputs of this stage: bits [LE-LZS, S) of the register index are zero (the bits above S were filled
+            // in by the earlier degenerate stages)
+#pragma unroll
+            for (int i = 0; i < (1 << LE); ++i) {
+                if ((i & d) || ((i >> (LE - LZS)) & ((1 << (S - (LE - LZS))) - 1))) continue;
+                x[i + d] = (SHIFT == 0 && (i & (d - 1)) == 0) ? x[i] : mont_mul(x[i], w[i & (d - 1)]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (1 << LE); ++i) {
+                if (i & d) continue;
+                const uint32_t u = x[i], v = x[i + d];
+                x[i] = bb_add(u, v);
+                if (SHIFT == 0 && (i & (d - 1)) == 0) x[i + d] = bb_sub(u, v);
+                else x[i + d] = mont_dot_sub(u, v, w[i & (d - 1)], nw[i & (d - 1)]);
+            }
+        }
+        if constexpr (S > 0) stages_lz<LE, SHIFT, LZ, S - 1>(x, tw1, low, uni);
+    }
+
     // step-1 slice of the packed stage table: stages LE2 .. LM-1 = words [2^LE2 - 1, 2^LM - 1)
     static constexpr uint32_t TW1_WORDS = TWO_STEP ? M - E2 : 0;
     static TOYNI_HD const uint32_t* tw1_global(const PassArgs& a) { return a.stage_tw + (E2 - 1u); }
@@ -338,11 +385,16 @@ struct Pass {
     // ---- the pieces of a pass, in the order a workgroup runs them ---------------------------------------
     // (a) HBM -> registers: E1 elements of the thread's column / row, r = lo + i * E2
     //     (registers [I0, I1) only: the persistent kernel prefetches a leading part of the next tile)
-    template <uint32_t I0 = 0, uint32_t I1 = E1>
+    //     LZ > 0: only rows r < M >> LZ exist in the input (the rest is the implied zero padding): registers
+    //     i >= E1 >> LZ are not loaded, and when LZ >= LE1 the one remaining load is guarded by lo < nz_rows.
+    template <uint32_t I0 = 0, uint32_t I1 = E1, int LZ = 0>
     static TOYNI_HD void load_tile(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1]) {
+        static_assert(LZ == 0 || KIND == KIND_COL, "zero-padded input is a first (column) pass feature");
+        constexpr uint32_t NZ = E1 >> (LZ < LE1 ? LZ : LE1);
         uint32_t c, lo;
         coords1(tid, c, lo);
-        const bool live = KIND != KIND_ROW_N || c < t.valid_c;  // only single-pass row tiles can be ragged
+        const bool live = (KIND != KIND_ROW_N || c < t.valid_c)  // only single-pass row tiles can be ragged
+                          && (LZ < LE1 || lo < a.nz_rows);
         // in_offset is linear in r: register i sits at off0 + i * step (bytes)
         const uint32_t off0 = in_offset(a, t, c, lo) << 2;
         const uint32_t step = (in_offset(a, t, 0u, E2) - in_offset(a, t, 0u, 0u)) << 2;
@@ -350,7 +402,7 @@ struct Pass {
         const char* base = reinterpret_cast<const char*>(t.in);
         if (live) {
 #pragma unroll
-            for (uint32_t i = I0; i < I1; ++i) x[i] = ld32(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0);
+            for (uint32_t i = I0; i < I1; ++i) x[i] = i < NZ ? ld32(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0) : 0u;
         } else {
 #pragma unroll
             for (uint32_t i = I0; i < I1; ++i) x[i] = 0u;
@@ -371,23 +423,28 @@ struct Pass {
         }
         return r;
     }
+    template <int LZ = 0>
     static TOYNI_HD void in_scale(const PassArgs& a, const InSeedRaw& r, uint32_t (&x)[E1]) {
+        constexpr uint32_t NZ = E1 >> (LZ < LE1 ? LZ : LE1);  // zero-padded input: only these registers hold data
         if (KIND != KIND_ROW_T && a.cs_mode == 1u) {
             uint32_t tw = mont_mul(r.hi, r.lo);
 #pragma unroll
-            for (uint32_t i = 0; i < E1; ++i) {
+            for (uint32_t i = 0; i < NZ; ++i) {
                 x[i] = mont_mul(x[i], tw);
-                if (i + 1 < E1) { tw = mont_mul(tw, a.cs_g); TOYNI_PIN(tw); }
+                if (i + 1 < NZ) { tw = mont_mul(tw, a.cs_g); TOYNI_PIN(tw); }
             }
         }
     }
 
     // (b) the LE1 high-bit stages in registers, then park the tile in LDS (two-step) or finish (single-step)
+    template <int LZ = 0>
     static TOYNI_HD void step1(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1], uint32_t* lds, const Uniform& uni,
                                const uint32_t* tw1) {
+        static_assert(LZ == 0 || TWO_STEP, "zero-padded input needs a two-step pass");
         uint32_t c, lo;
         coords1(tid, c, lo);
-        stages<LE1, LE2>(x, tw1, lo, uni.w);
+        if constexpr (LZ == 0) stages<LE1, LE2>(x, tw1, lo, uni.w);
+        else stages_lz<LE1, LE2, LZ, LE1 - 1>(x, tw1, lo, uni.w);
         if (TWO_STEP) {
             const uint32_t base = lds_word(c, 0u, lo);
 #pragma unroll
@@ -434,12 +491,13 @@ struct Pass {
 
     // Whole tile, one thread, in program order (single-step kinds; tests/emu runs the two-step kinds as
     // phase1 for every thread, then phase2 for every thread -- the pass' one data barrier).
+    template <int LZ = 0>
     static TOYNI_HD void phase1(const PassArgs& a, uint32_t tile_id, uint32_t tid, uint32_t* lds) {
         const Tile t = tile_of(a, tile_id);
         uint32_t x[E1];
-        load_tile(a, t, tid, x);
-        in_scale(a, in_seed_issue(a, t, tid), x);
-        step1(a, t, tid, x, lds, load_uniform(a), tw1_global(a));
+        load_tile<0, E1, LZ>(a, t, tid, x);
+        in_scale<LZ>(a, in_seed_issue(a, t, tid), x);
+        step1<LZ>(a, t, tid, x, lds, load_uniform(a), tw1_global(a));
     }
     static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
         const Tile t = tile_of(a, tile_id);

@@ -6,6 +6,7 @@
 // Plain C++ (shared with tests/emu).
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 #include <vector>
 
 #include "bb_field.hpp"
@@ -164,6 +165,34 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f) {
     return false;
 }
 
+// First pass of a low-degree extension (zero-padded input, PassArgs::in_prefix_log): the same column shapes with the
+// zero fraction as a compile-time parameter, f(Pass{}, std::integral_constant<int, LZ>{}), LZ = 1..5.
+template <class F>
+inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
+#define TOYNI_LZ_CASES(PASS)                                                                 \
+    switch (lz) {                                                                            \
+        case 1: f(PASS{}, std::integral_constant<int, 1>{}); return true;                    \
+        case 2: f(PASS{}, std::integral_constant<int, 2>{}); return true;                    \
+        case 3: f(PASS{}, std::integral_constant<int, 3>{}); return true;                    \
+        case 4: f(PASS{}, std::integral_constant<int, 4>{}); return true;                    \
+        case 5: f(PASS{}, std::integral_constant<int, 5>{}); return true;                    \
+        default: return false;                                                               \
+    }
+#define TOYNI_COMMA ,
+    if (log_m == 6) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
+    if (log_m == 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
+    if (log_m == 8) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 5>) }
+    if (log_m == 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 4 TOYNI_COMMA 5>) }
+    if (log_m == 10) {
+        if (log_tiles32 >= 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 5>) }
+        else if (log_tiles32 >= 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 4>) }
+        else { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 3>) }
+    }
+#undef TOYNI_COMMA
+#undef TOYNI_LZ_CASES
+    return false;
+}
+
 // Walks the passes of `batch` transforms src -> dst (src == dst allowed; `work` holds batch * n words and is
 // needed when npasses > 1).  `tables` points at the direction's blob wherever the executor can read it
 // (device memory for the HIP launcher, host memory for tests/emu).  launch(PassType{}, args, nblocks).
@@ -178,10 +207,15 @@ struct CosetTables {
     uint32_t s = 1;  // plain canonical
 };
 
+// lde_log > 0 (forward, multi-pass plans only): `src` holds the n >> lde_log leading words of every transform, the
+// rest of the input is implied zeros -- the first pass runs its zero-aware variant (launch receives LZ = min(lde_log, 5)
+// as std::integral_constant; 0 for every other launch).
 template <class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
-                          uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables()) {
+                          uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables(),
+                          int lde_log = 0) {
     if (plan.log_n == 0 || batch == 0) return true;  // n = 1: identity
+    if (lde_log && (inverse || plan.npasses < 2 || lde_log > plan.pass[0].log_m)) return false;
     const uint64_t total_log = (uint64_t)plan.log_n;
     for (int p = 0; p < plan.npasses; ++p) {
         const PassPlan& pp = plan.pass[p];
@@ -193,6 +227,8 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         a.tw_hi = tables + pp.hi_off;
         a.tw_lowbits = pp.lowbits;
         a.log_S = (uint32_t)pp.log_s;
+        a.in_prefix_log = (uint32_t)(pp.log_s + pp.log_m - (p == 0 ? lde_log : 0));
+        a.nz_rows = (1u << pp.log_m) >> (p == 0 ? lde_log : 0);
         a.scale = (inverse && p == 0) ? plan.scale_inv : 0u;  // src/ntt.rs:62-65, fused
         a.log_n = (uint32_t)plan.log_n;
         a.log_M1 = (uint32_t)plan.pass[0].log_m;
@@ -204,7 +240,7 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
             const uint64_t tiles32 = (batch << (total_log - (uint64_t)pp.log_m)) >> 5;
             while ((2ull << log_tiles32) <= tiles32) ++log_tiles32;
         }
-        bool ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) {
+        auto body = [&](auto pass, auto lzc) {
             using P = decltype(pass);
             // forward coset FFT scales the INPUT of the first pass by s^j, inverse scales the OUTPUT of the last by s^k
             const bool cs_here = cs.lo && (inverse ? p == plan.npasses - 1 : p == 0);
@@ -223,8 +259,11 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
             uint64_t nblocks;
             if (pp.kind == KIND_ROW_N) nblocks = (batch + P::C - 1) / P::C;
             else nblocks = (batch << (total_log - P::LM)) / P::C;  // tiles of C columns / rows, each M long
-            launch(pass, a, nblocks);
-        });
+            launch(pass, lzc, a, nblocks);
+        };
+        bool ok;
+        if (p == 0 && lde_log) ok = dispatch_pass_lz(pp.log_m, log_tiles32, lde_log < 5 ? lde_log : 5, body);
+        else ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); });
         if (!ok) return false;
     }
     return true;
@@ -253,6 +292,8 @@ inline bool slab_pass(const NttPlan& plan, const uint32_t* tables, bool inverse,
     a.stage_tw = tables + pp.stage_off;
     a.tw_lowbits = pp.lowbits;
     a.log_S = (uint32_t)log_c;
+    a.in_prefix_log = (uint32_t)(log_c + pp.log_m);
+    a.nz_rows = 1u << pp.log_m;
     if (!inverse) {
         a.tw_lo = tables + pp.lo_off;
         a.tw_hi = tables + pp.hi_off;

@@ -38,11 +38,14 @@ template <class P> struct PassKindOf;
 template <int K, int A, int B, int C> struct PassKindOf<Pass<K, A, B, C>> { static constexpr int value = K; };
 template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
 
-template <class P, int PF>
+// LZ > 0: first pass of a low-degree extension -- the input holds only the leading n >> LZ words of every transform
+// (the zero padding is implied): fewer loads, and the top LZ stages of step 1 degenerate to one multiply per output.
+template <class P, int PF, int LZ = 0>
 __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const PassArgs a, const uint32_t ntiles) {
     __shared__ uint32_t lds[(P::LDS_WORDS + P::TW1_WORDS) ? (P::LDS_WORDS + P::TW1_WORDS) : 1];
     const uint32_t tid = threadIdx.x;
     if constexpr (!P::TWO_STEP) {
+        static_assert(LZ == 0, "single-step passes take whole inputs");
         for (uint32_t v = blockIdx.x; v < ntiles; v += gridDim.x) P::phase1(a, P::tile_order(v, ntiles), tid, lds);
     } else {
         constexpr uint32_t NPF = PF < 0 ? 0u : ((uint32_t)PF > P::E1 ? P::E1 : (uint32_t)PF);
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
         uint32_t* lds_tw1 = lds + P::LDS_WORDS;
         uint32_t x[P::E1];
         typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
-        P::template load_tile<0, NPF>(a, t, tid, x);
+        P::template load_tile<0, NPF, LZ>(a, t, tid, x);
         typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
         typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
         const typename P::Uniform uni = P::load_uniform(a);  // step-2 twiddles, SGPR-resident for the whole loop
@@ -66,9 +69,9 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
             static_assert(P::G2 * P::E2 == P::E1 && P::E1 <= 63, "stores per tile per thread");
             if constexpr (kind_of<P>() != KIND_ROW_N) TOYNI_WAIT_VMEM_ALLOW(P::E1);
             else TOYNI_WAIT_VMEM0();
-            P::template load_tile<NPF, P::E1>(a, t, tid, x);
-            P::in_scale(a, inraw, x);  // forward coset FFT only (uniform branch)
-            P::step1(a, t, tid, x, lds, uni, lds_tw1);
+            P::template load_tile<NPF, P::E1, LZ>(a, t, tid, x);
+            P::template in_scale<LZ>(a, inraw, x);  // forward coset FFT only (uniform branch)
+            P::template step1<LZ>(a, t, tid, x, lds, uni, lds_tw1);
             typename P::Seeds seeds = P::seeds_finish(a, raw);
 #pragma unroll
             for (uint32_t g = 0; g < P::G2; ++g) { TOYNI_PIN(seeds.g[g].a0); TOYNI_PIN(seeds.g[g].g); }  // materialised HERE
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
             typename P::Tile tn = t;
             if (more) {
                 tn = P::tile_of(a, P::tile_order(vn, ntiles));
-                P::template load_tile<0, NPF>(a, tn, tid, x);  // prefetch
+                P::template load_tile<0, NPF, LZ>(a, tn, tid, x);  // prefetch
                 raw = P::seeds_issue(a, tn, tid);              // and the next tile's seed lookups, still ahead of the stores
                 inraw = P::in_seed_issue(a, tn, tid);
             }
@@ -411,10 +414,14 @@ int prefetch_depth() {
     return depth;
 }
 
-template <class P>
+template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
-    if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    if constexpr (LZ > 0) {  // low-degree-extension first pass: one variant (the prefetch knob applies to the whole-input kernels)
+        hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    } else {
+        if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    }
 }
 
 // Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
@@ -437,9 +444,11 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 
 // Enqueue the passes of `batch` transforms on stream s (d_in == d_out allowed).  shift != 1: the coset scaling of
 // BabyBearDomain::fft / ifft is fused into the first / last pass.
-int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u) {
+int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u,
+                      int lde_log = 0) {
     if (batch == 0) return 0;
     const size_t n = c->n;
+    const size_t n_in = n >> lde_log;  // lde_log > 0: the input holds the leading n >> lde_log words of every transform
     CosetTables cs;
     if (shift != 1u && c->plan.log_n > 0) {
         ShiftTable* st = nullptr;
@@ -470,9 +479,10 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
         int pass_index = 0;
-        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n, c->d_work, d_out + b0 * n, nb,
-                                [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n_in, c->d_work, d_out + b0 * n, nb,
+                                [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
                                     using P = decltype(pass);
+                                    constexpr int LZ = decltype(lzc)::value;
                                     const int p = pass_index++;
                                     if (err != hipSuccess) return;
                                     toyni_ntt_ctx::TimingRec rec{nullptr, nullptr, inverse ? 1 : 0, p};
@@ -481,13 +491,13 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                         if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
                                         (void)hipEventRecord(rec.e0, s);
                                     }
-                                    launch_pass<P>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
+                                    launch_pass<P, LZ>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
                                     err = hipGetLastError();
                                     if (c->timing) {
                                         (void)hipEventRecord(rec.e1, s);
                                         c->timing_recs.push_back(rec);
                                     }
-                                }, cs);
+                                }, cs, lde_log);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
     }
@@ -648,6 +658,27 @@ int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_o
     // forward: scale by shift^i then NTT (src/math/domain.rs:111,121); inverse: INTT then scale by shift^-i (:99-100);
     // shift == 1 is the plain transform (:155,166).  The scaling is fused into the first / last pass.
     return enqueue_transform(c, d_in, d_out, batch, inverse != 0, s, shift);
+}
+
+// Low-degree extension (src/fibonacci.rs:101-103 / BabyBearDomain::fft on a coefficient vector shorter than the domain,
+// src/math/domain.rs:107-123): forward coset transform of coefficients zero-padded to n.  The padding is never
+// materialised: the first pass reads the n >> log_blowup words that exist and skips the butterflies whose partner is zero.
+int toyni_lde_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream) {
+    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n) return TOYNI_E_RANGE;
+    if (log_blowup && d_coeffs == d_out) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (log_blowup == 0) return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift);
+    if (c->plan.npasses >= 2 && (int)log_blowup <= c->plan.pass[0].log_m)
+        return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift, (int)log_blowup);
+    // single-pass sizes (n <= 1024) and blow-ups beyond the first pass: materialise the padding, transform in place
+    if (batch == 0) return TOYNI_OK;
+    const size_t n = c->n, n_in = n >> log_blowup;
+    HIPCHK(hipMemsetAsync(d_out, 0, batch * n * sizeof(uint32_t), s));
+    HIPCHK(hipMemcpy2DAsync(d_out, n * sizeof(uint32_t), d_coeffs, n_in * sizeof(uint32_t), n_in * sizeof(uint32_t), batch, hipMemcpyDeviceToDevice, s));
+    return enqueue_transform(c, d_out, d_out, batch, false, s, shift);
 }
 
 int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int inverse, void* stream) {
@@ -1093,7 +1124,7 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
     int pass_index = 0;
     hipError_t err = hipSuccess;
     bool ok = for_each_pass(c->plan, tables, inverse != 0, d_data, c->d_work, d_data, batch,
-                            [&](auto pass, const PassArgs& a, uint64_t nblocks) {
+                            [&](auto pass, auto, const PassArgs& a, uint64_t nblocks) {
                                 using P = decltype(pass);
                                 if (err != hipSuccess) return;
                                 const unsigned grid = persistent_grid<P>(c, nblocks);

@@ -113,6 +113,10 @@ class NttContext:
         else:
             check(lib.toyni_coset_ntt_device(self.handle, d_in, d_out, batch, shift, int(inverse), stream or None), "GPU coset NTT failed")
 
+    def lde_device(self, d_coeffs: int, d_out: int, batch: int, log_blowup: int, shift: int = 1, stream: int = 0) -> None:
+        """Low-degree extension: forward coset transform of batch vectors of n >> log_blowup coefficients, zero padding implied."""
+        check(lib.toyni_lde_device(self.handle, d_coeffs, d_out, batch, log_blowup, shift, stream or None), "GPU LDE failed")
+
     def run_host_ext(self, values4: np.ndarray, inverse: bool, shift: int = 1) -> None:
         """n Ext elements ([n, 4] u64, AoS) in place: the four coordinate transforms as one batch, one PCIe round trip."""
         v = _as_u64(values4)
