@@ -207,8 +207,13 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     poly[:MASK_DEGREE] = (poly[:MASK_DEGREE] - r) % P
     poly[n:n + MASK_DEGREE] = (poly[n:n + MASK_DEGREE] + r) % P
     trace_poly = poly[: n + MASK_DEGREE].clone()                  # coefficients, for the OOD evaluations
-    trace_lde = poly.to(torch.int32)
-    ntt_dev(ctx_N, trace_lde, False, shift=COSET_SHIFT)            # LDE: one coset FFT
+    # LDE: one coset FFT of the masked polynomial (n + MASK_DEGREE coefficients); the zero padding up to N is
+    # implied, not stored (toyni_lde_device: the first pass reads only the words that exist)
+    log_c = (n + MASK_DEGREE - 1).bit_length()                     # compact length 2^log_c >= n + MASK_DEGREE
+    assert log_c <= log_N
+    compact = poly[: 1 << log_c].to(torch.int32).contiguous()
+    trace_lde = torch.empty(N, dtype=torch.int32, device=dev)
+    ctx_N.lde_device(compact.data_ptr(), trace_lde.data_ptr(), 1, log_N - log_c, COSET_SHIFT, stream=stream)
     trace_tree = DeviceTree(trace_lde, rng, True, stream)
     trace_commitment = trace_tree.root()
     lap("1_interpolate_mask_lde_commit")
