@@ -352,6 +352,30 @@ def main():
             th = (time.perf_counter() - t0h) / reps_h
             extras[f"host_slice_n2^{ln}"] = {"ms": th * 1e3, "elements_per_s": nn / th, "note": "ntt_cuda-shaped call: H2D u64 + kernels + D2H u64, pageable host memory"}
             c1.destroy()
+        # ---- BabyBearDomain::fft(coeffs) through the host-slice entry points (PCIe inclusive): pad on the host + full upload
+        #      (what the reference does, src/math/domain.rs:108-109) vs toyni_lde_host (coefficients only on the way in)
+        c21 = toyni_amd.NttContext(1 << 21, device=dev.index)
+        hc = np.random.default_rng(3).integers(0, P, 1 << 16, dtype=np.uint64)
+
+        def host_pad():
+            v = np.zeros(1 << 21, dtype=np.uint64)
+            v[: hc.size] = hc
+            c21.run_host(v, False, shift=7)
+            return v
+
+        ref_h = host_pad()
+        assert (c21.lde_host(hc, shift=7) == ref_h).all()
+        t0h = time.perf_counter()
+        for _ in range(5):
+            host_pad()
+        t_pad_h = (time.perf_counter() - t0h) / 5
+        t0h = time.perf_counter()
+        for _ in range(5):
+            c21.lde_host(hc, shift=7)
+        t_lde_h = (time.perf_counter() - t0h) / 5
+        extras["host_lde_2^16_to_2^21"] = {"ms_host_pad_then_ntt": t_pad_h * 1e3, "ms_lde_host": t_lde_h * 1e3,
+                                            "note": "domain.fft(coeffs) on host slices, coset shift 7, pageable memory; PCIe inclusive"}
+        c21.destroy()
         # ---- the other headline size, batched: 64 x n = 2^24 (4 GiB, three sweeps per transform)
         c24 = toyni_amd.NttContext(1 << 24, device=dev.index)
         n24, b24 = 1 << 24, 64

@@ -96,6 +96,10 @@ int toyni_coset_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, uin
  * words that exist and skips the butterflies whose partner is a padding zero.  Out of place; d_out holds batch * n words.
  * Identical results to zero-padding by hand and calling toyni_coset_ntt_device. */
 int toyni_lde_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream);
+/* Host-slice form = BabyBearDomain::fft(coeffs) in one call (src/math/domain.rs:107-123): ncoeffs <= n coefficients in
+ * (any count; u64 elements, reduced mod p like BabyBear::new), n evaluations on shift * <w_n> out.  Only the
+ * coefficients are uploaded (the reference pads on the host and uploads n elements).  Blocking. */
+int toyni_lde_host(toyni_ntt_ctx* ctx, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift);
 
 /* Extension-field transforms, fft_ext / ifft_ext (src/math/domain.rs:129-151): n Ext elements = 4 words each (AoS,
  * #[repr(C)] Ext { c: [BabyBear; 4] }).  The transform is base-linear, so it is the four coordinate transforms -- issued

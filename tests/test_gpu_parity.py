@@ -613,6 +613,21 @@ def test_lde_matches_padded_transform_and_oracle(ta, log_n, log_blowup, batch, s
     assert (dev_transform(ta, padded.reshape(-1), n, batch, False, shift=shift) == got).all()
 
 
+@pytest.mark.parametrize("log_n,ncoeffs", [(0, 1), (3, 3), (8, 0), (8, 256), (10, 40), (11, 1), (12, 100), (16, 2048), (16, 2049),
+                                           (18, 8192), (20, 32768), (20, 1 << 20), (21, 65676)])
+def test_lde_host_is_domain_fft(ta, log_n, ncoeffs):
+    # BabyBearDomain::fft(coeffs), src/math/domain.rs:107-123, through the one-call host entry point: any coefficient
+    # count (the device pads the compact vector up to a power of two, the rest of the padding is implied)
+    n = 1 << log_n
+    coeffs = oracle.splitmix(ncoeffs, 6000 + log_n) if ncoeffs else np.zeros(0, dtype=np.uint64)
+    got = ta.ntt.get_or_create_ctx(n).lde_host(coeffs, shift=7)
+    want = oracle.domain_fft(coeffs, n, 7) if ncoeffs else np.zeros(n, dtype=np.uint64)
+    assert got.dtype == np.uint64 and (got == want).all()
+    if ncoeffs:                                      # non-canonical u64 inputs behave like BabyBear::new (src/babybear.rs:26-30)
+        big = coeffs + np.uint64(P) * np.uint64(3)
+        assert (ta.ntt.get_or_create_ctx(n).lde_host(big, shift=7) == want).all()
+
+
 def test_lde_rejects_bad_arguments(ta):
     ctx = ta.ntt.get_or_create_ctx(1 << 12)
     buf = DevBuf(ta, 4 << 12)
@@ -621,6 +636,9 @@ def test_lde_rejects_bad_arguments(ta):
     assert lib.toyni_lde_device(ctx.handle, buf.ptr, buf.ptr, 1, 13, 7, None) == 10006      # blow-up larger than n
     assert lib.toyni_lde_device(ctx.handle, buf.ptr, buf.ptr, 1, 1, 0, None) == 10006       # shift 0
     assert lib.toyni_lde_device(ctx.handle, None, buf.ptr, 1, 1, 7, None) == 10002
+    host = np.zeros(1 << 13, dtype=np.uint64)
+    assert lib.toyni_lde_host(ctx.handle, host.ctypes.data, (1 << 12) + 1, host.ctypes.data, 7) == 10006   # more coefficients than points
+    assert lib.toyni_lde_host(ctx.handle, host.ctypes.data, 4, host.ctypes.data, 0) == 10006                # shift 0
     buf.free()
 
 

@@ -370,6 +370,8 @@ struct toyni_ntt_ctx {
     size_t data32_words = 0;
     uint64_t* d_stage64 = nullptr;   // H2D / D2H staging on the reference's u64 layout
     size_t stage64_elems = 0;
+    uint32_t* d_lde32 = nullptr;     // compact coefficient vector of toyni_lde_host
+    size_t lde32_words = 0;
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
@@ -592,6 +594,7 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         (void)hipFree(c->d_work);
         (void)hipFree(c->d_data32);
         (void)hipFree(c->d_stage64);
+        (void)hipFree(c->d_lde32);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
         (void)hipFree(c->d_ones);
         for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -663,13 +666,7 @@ int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_o
 // Low-degree extension (src/fibonacci.rs:101-103 / BabyBearDomain::fft on a coefficient vector shorter than the domain,
 // src/math/domain.rs:107-123): forward coset transform of coefficients zero-padded to n.  The padding is never
 // materialised: the first pass reads the n >> log_blowup words that exist and skips the butterflies whose partner is zero.
-int toyni_lde_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream) {
-    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
-    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n) return TOYNI_E_RANGE;
-    if (log_blowup && d_coeffs == d_out) return TOYNI_E_RANGE;
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard guard(c->device);
-    hipStream_t s = (hipStream_t)stream;
+static int enqueue_lde(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, hipStream_t s) {
     if (log_blowup == 0) return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift);
     if (c->plan.npasses >= 2 && (int)log_blowup <= c->plan.pass[0].log_m)
         return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift, (int)log_blowup);
@@ -679,6 +676,45 @@ int toyni_lde_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out
     HIPCHK(hipMemsetAsync(d_out, 0, batch * n * sizeof(uint32_t), s));
     HIPCHK(hipMemcpy2DAsync(d_out, n * sizeof(uint32_t), d_coeffs, n_in * sizeof(uint32_t), n_in * sizeof(uint32_t), batch, hipMemcpyDeviceToDevice, s));
     return enqueue_transform(c, d_out, d_out, batch, false, s, shift);
+}
+
+int toyni_lde_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream) {
+    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n) return TOYNI_E_RANGE;
+    if (log_blowup && d_coeffs == d_out) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    return enqueue_lde(c, d_coeffs, d_out, batch, log_blowup, shift, (hipStream_t)stream);
+}
+
+// BabyBearDomain::fft(coeffs) as ONE call on host slices (src/math/domain.rs:107-123): `ncoeffs` <= n coefficients in, n
+// evaluations on shift * <w_n> out.  Only the coefficients cross PCIe on the way in (the reference pads on the host and
+// uploads all n elements, src/ntt.rs:233 via cuda/ntt_kernel.cu:254); the padding is implied on the device.
+int toyni_lde_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift) {
+    if (!c || !h_out || (!h_coeffs && ncoeffs)) return TOYNI_E_NULL;
+    shift %= BB_P;
+    if (shift == 0 || ncoeffs > (size_t)c->n) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const size_t n = c->n;
+    if (ncoeffs == 0) { std::memset(h_out, 0, n * sizeof(uint64_t)); return TOYNI_OK; }  // the zero polynomial
+    size_t compact = 1;
+    while (compact < ncoeffs) compact <<= 1;
+    const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, n, sizeof(uint64_t)))) return rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, n, sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, compact, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_stage64, h_coeffs, ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(ncoeffs)), dim3(256), 0, s, c->d_stage64, c->d_lde32, ncoeffs);
+    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(c->d_lde32 + ncoeffs, 0, (compact - ncoeffs) * sizeof(uint32_t), s));
+    if ((rc = enqueue_lde(c, c->d_lde32, c->d_data32, 1, log_blowup, (uint32_t)shift, s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->d_stage64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return TOYNI_OK;
 }
 
 int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int inverse, void* stream) {

@@ -37,10 +37,8 @@ class BabyBearDomain:
         self._require_gpu()
         c = np.asarray(coeffs, dtype=np.uint64)
         assert c.size <= self.size
-        values = np.zeros(self.size, dtype=np.uint64)
-        values[: c.size] = c
-        _ntt.get_or_create_ctx(self.size).run_host(values, inverse=False, shift=self.shift)
-        return values
+        # the zero padding of :109 is implied on the device: only the coefficients cross PCIe on the way in
+        return _ntt.get_or_create_ctx(self.size).lde_host(c, shift=self.shift)
 
     def ifft(self, evals) -> np.ndarray:
         """src/math/domain.rs:85-102: INTT, then scale by shift^-i."""

@@ -117,6 +117,13 @@ class NttContext:
         """Low-degree extension: forward coset transform of batch vectors of n >> log_blowup coefficients, zero padding implied."""
         check(lib.toyni_lde_device(self.handle, d_coeffs, d_out, batch, log_blowup, shift, stream or None), "GPU LDE failed")
 
+    def lde_host(self, coeffs: np.ndarray, shift: int = 1) -> np.ndarray:
+        """BabyBearDomain::fft(coeffs) in one call: len(coeffs) <= n coefficients up, n evaluations on shift * <w_n> back."""
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        out = np.empty(self.n, dtype=np.uint64)
+        check(lib.toyni_lde_host(self.handle, c.ctypes.data if c.size else None, c.size, out.ctypes.data, shift), "GPU LDE failed")
+        return out
+
     def run_host_ext(self, values4: np.ndarray, inverse: bool, shift: int = 1) -> None:
         """n Ext elements ([n, 4] u64, AoS) in place: the four coordinate transforms as one batch, one PCIe round trip."""
         v = _as_u64(values4)
