@@ -38,6 +38,7 @@ using namespace toyni;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
+static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
                           int lde_log = 0) {
     const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
@@ -51,6 +52,27 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         cs.hi = cblob.data() + hi_off;
     }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
+    if (use_lds && plan.lds_la && !lde_log) {      // n = 2^11 .. 2^15: the single-sweep kernel, phase by phase (two barriers)
+        bool okl = lds_transform(plan, blob.data(), inverse, src, dst, batch, [&](auto pass, const LdsArgs& g, uint64_t ntiles) {
+            using L = decltype(pass);
+            std::vector<uint32_t> lds(L::LDS_WORDS, 0xDEADBEEFu);
+            std::vector<uint32_t> regs((size_t)L::T * L::E);
+            for (uint64_t tile = 0; tile < ntiles; ++tile) {
+                for (uint32_t tid = 0; tid < L::T; ++tid) {
+                    uint32_t (&x)[L::E] = *reinterpret_cast<uint32_t (*)[L::E]>(&regs[(size_t)tid * L::E]);
+                    L::loadA(g, tile, tid, x);      // every load of the tile before any store (in-place transforms)
+                }
+                for (uint32_t tid = 0; tid < L::T; ++tid) {
+                    uint32_t (&x)[L::E] = *reinterpret_cast<uint32_t (*)[L::E]>(&regs[(size_t)tid * L::E]);
+                    L::phaseA(g, tid, x, L::seedsA(g, tid), L::load_uniform(g), lds.data());
+                }
+                for (uint32_t tid = 0; tid < L::T; ++tid) L::phaseB(tid, lds.data(), L::tw1_global(g));
+                for (uint32_t tid = 0; tid < L::T; ++tid) L::phaseC(g, tile, tid, lds.data(), L::load_uniform(g));
+            }
+        }, cs);
+        CHECK(okl, "lds transform rejected log_n=%d", plan.log_n);
+        return;
+    }
     bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
         constexpr int LZ = decltype(lzc)::value;
@@ -327,6 +349,13 @@ int main(int argc, char** argv) {
     test_field();
     std::printf("field ok=%d\n", failures == 0);
     for (int log_n = 0; log_n <= max_log; ++log_n) {
+        if (log_n >= 11 && log_n <= 15) {           // these sizes have two executors: first the two-pass plan ...
+            use_lds = false;
+            test_ntt(log_n, 3, 0);
+            test_coset(log_n, 2, 7);
+            use_lds = true;                         // ... then (below) the single-sweep kernel, incl. ragged tiles
+            test_ntt(log_n, (32u >> (log_n - 10)) + 1, 0);
+        }
         test_ntt(log_n, 1, 0);
         test_ntt(log_n, log_n <= 10 ? 70 : 3, 0);   // ragged row tiles for the single-pass kinds
         if (log_n == 8) test_ntt(log_n, 1, 1);      // src/ntt.rs:263-287 input

@@ -585,6 +585,33 @@ def test_slab_entry_points_reject_bad_shapes(ta):
     buf.free()
 
 
+def test_two_pass_plan_of_the_single_sweep_sizes(ta):
+    # n = 2^11 .. 2^15 normally run the single-sweep LDS kernel; their two-pass plan (whose first pass the LDE and slab
+    # entry points use) stays selectable with TOYNI_NO_LDS_KERNEL=1 -- checked in a child process (the knob is read once)
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, oracle, toyni_amd\n"
+        "from test_gpu_parity import dev_transform\n"
+        "for log_n in range(11, 16):\n"
+        "    n = 1 << log_n\n"
+        "    assert toyni_amd.NttContext(n).passes == 2\n"
+        "    x = oracle.splitmix(3 * n, 777 + log_n).astype(np.uint32)\n"
+        "    f = dev_transform(toyni_amd, x, n, 3, False)\n"
+        "    i = dev_transform(toyni_amd, x, n, 3, True, shift=7)\n"
+        "    for b in range(3):\n"
+        "        row = x[b * n:(b + 1) * n].astype(np.uint64)\n"
+        "        assert (f[b * n:(b + 1) * n] == oracle.ntt(row)).all()\n"
+        "        assert (i[b * n:(b + 1) * n] == oracle.domain_ifft(row, 7)).all()\n"
+        "print('TWO PASS OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOYNI_NO_LDS_KERNEL="1", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests")]))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0 and "TWO PASS OK" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+    assert ta.NttContext(1 << 13).passes == 1                       # this process: the single-sweep kernel
+
+
 # ---------------------------------------------------------------- low-degree extension (src/fibonacci.rs:101-103)
 @pytest.mark.parametrize("log_n,log_blowup,batch,shift", [
     (11, 5, 3, 7), (12, 1, 2, 7), (14, 3, 5, 1), (16, 5, 4, 7), (16, 8, 2, 7), (18, 2, 3, 7), (20, 5, 2, 7), (20, 1, 1, 7),

@@ -18,7 +18,8 @@ def main():
     data = torch.randint(0, P, (TOTAL,), dtype=torch.int32, device=dev)
     ptr = data.data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
-    for log_n in range(4, 28):
+    lo, hi = (int(v) for v in os.environ.get("SWEEP_RANGE", "4:28").split(":"))
+    for log_n in range(lo, hi):
         n = 1 << log_n
         batch = TOTAL // n
         ctx = toyni_amd.NttContext(n)

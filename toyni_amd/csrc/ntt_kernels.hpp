@@ -505,6 +505,141 @@ struct Pass {
     }
 };
 
+// ---- single-sweep transforms for n = 2^11 .. 2^15: the whole transform stays in one workgroup's LDS ----
+// n = M_a * 1024 with M_a = 2^LA (LA = 1..5).  A tile is R = 32 / M_a consecutive transforms of the batch = 32 rows of
+// 1024 words = one contiguous 128 KiB block of HBM, read once and written once (the two-pass plan moves it twice).
+//   phase A  thread <-> column j' (= tid, 4-KiB coalesced rows): the M_a-point transforms over j_a for every transform of
+//            the tile, in registers, uniform twiddles; times w_n^(j' k_a) (running product of the thread's own w_n^j');
+//            row (r, k_a) of the tile is parked in LDS
+//   phase B  the 1024-point row transforms, high five stage bits (per-thread twiddles), in place in LDS
+//   phase C  low five stage bits (uniform twiddles) and the store: X_r[k_a + M_a k_b].  Lanes run over (k_a, low bits of
+//            k_b), so a wave writes whole contiguous runs for every M_a.
+// Row layout in LDS as for the row kinds above: word = row * PITCH + hi * 33 + low, PITCH = 1 mod 32 (conflict-free for
+// phase A's writes, phase B's strided and phase C's per-row accesses).
+constexpr uint32_t BB_MONT_ONE = (uint32_t)((1ull << 32) % BB_P);
+
+struct LdsArgs {
+    const uint32_t* in;
+    uint32_t* out;
+    const uint32_t* stage_a;   // packed stage table of the M_a-point transform (uniform twiddles)
+    const uint32_t* stage_b;   // packed stage table of the 1024-point transform
+    const uint32_t* gtab;      // w_n^j', j' < 1024
+    uint32_t scale;            // Montgomery form of n^-1 (inverse transform), 0 = none
+    uint64_t batch;            // transforms; the last tile may be ragged
+    // coset scaling (PassArgs::cs_*): mode 1 = input x[j] *= s^j, mode 2 = output X[k] *= s^k; cs_g = s^1024 / s^(32 M_a)
+    const uint32_t* cs_lo;
+    const uint32_t* cs_hi;
+    uint32_t cs_lowbits;
+    uint32_t cs_mode;
+    uint32_t cs_g;
+};
+
+template <int LA>
+struct LdsPass {
+    static_assert(LA >= 1 && LA <= 5, "n = 2^11 .. 2^15");
+    static constexpr int LOG_N = LA + 10;
+    static constexpr uint32_t MA = 1u << LA, R = 32u >> LA, T = 1024u, E = 32u;
+    static constexpr uint32_t PITCH = 32u * 33u + 1u;           // 1057 = 1 mod 32
+    static constexpr uint32_t LDS_WORDS = 32u * PITCH;
+    static constexpr uint32_t TW1_WORDS = 1024u - 32u;          // stages 5..9 of the 1024-point stage table
+    static constexpr uint32_t NU = 16u;                         // uniform twiddles of a 32-point step
+    struct Uniform { uint32_t a[MA > 1 ? MA / 2 : 1]; uint32_t b[NU]; };
+
+    static TOYNI_HD Uniform load_uniform(const LdsArgs& g) {
+        Uniform u;
+#pragma unroll
+        for (uint32_t q = 0; q < MA / 2; ++q) u.a[q] = TOYNI_UNIFORM(g.stage_a[MA / 2 - 1u + q]);
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) u.b[q] = TOYNI_UNIFORM(g.stage_b[NU - 1u + q]);
+        return u;
+    }
+    static TOYNI_HD const uint32_t* tw1_global(const LdsArgs& g) { return g.stage_b + 31u; }
+    static TOYNI_HD uint32_t row_word(uint32_t row, uint32_t col) { return row * PITCH + (col >> 5) * 33u + (col & 31u); }
+
+    // phase A, loads: register r * MA + j_a = x_r[j_a * 1024 + j'] (zero for transforms beyond the batch)
+    static TOYNI_HD void loadA(const LdsArgs& g, uint64_t tile, uint32_t tid, uint32_t (&x)[E]) {
+        const uint64_t b0 = tile * R;
+        const uint32_t* base = g.in + (b0 << LOG_N);
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {
+            const bool live = b0 + r < g.batch;   // uniform
+#pragma unroll
+            for (uint32_t ja = 0; ja < MA; ++ja)
+                x[r * MA + ja] = live ? ld32(base, ((r << LOG_N) + (ja << 10) + tid) << 2) : 0u;
+        }
+    }
+    // the thread's own constants: w_n^j' and (forward coset transform) s^j'
+    struct Seeds { uint32_t g, cs_a; };
+    static TOYNI_HD Seeds seedsA(const LdsArgs& g, uint32_t tid) {
+        Seeds s{g.gtab[tid], 0u};
+        if (g.cs_mode == 1u) s.cs_a = mont_mul(g.cs_hi[tid >> g.cs_lowbits], g.cs_lo[tid & ((1u << g.cs_lowbits) - 1u)]);
+        return s;
+    }
+    static TOYNI_HD void phaseA(const LdsArgs& g, uint32_t tid, uint32_t (&x)[E], const Seeds& sd, const Uniform& uni, uint32_t* lds) {
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {
+            uint32_t (&xr)[MA] = *reinterpret_cast<uint32_t (*)[MA]>(&x[r * MA]);
+            if (g.cs_mode == 1u) {   // x[j] *= s^j, j = j_a * 1024 + j'
+                uint32_t tw = sd.cs_a;
+#pragma unroll
+                for (uint32_t ja = 0; ja < MA; ++ja) {
+                    xr[ja] = mont_mul(xr[ja], tw);
+                    if (ja + 1 < MA) { tw = mont_mul(tw, g.cs_g); TOYNI_PIN(tw); }
+                }
+            }
+            Pass<KIND_ROW_N, 5, 5, 3>::template stages<LA, 0>(xr, nullptr, 0u, uni.a);
+            // times w_n^(j' k_a) (and n^-1 on an inverse): k_a = b sits in register bitrev(b)
+            uint32_t tw = g.scale ? g.scale : BB_MONT_ONE;
+            if (g.scale) xr[0] = mont_mul(xr[0], tw);
+#pragma unroll
+            for (uint32_t b = 1; b < MA; ++b) {
+                tw = mont_mul(tw, sd.g);
+                TOYNI_PIN(tw);
+                xr[cx_bitrev(b, LA)] = mont_mul(xr[cx_bitrev(b, LA)], tw);
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < MA; ++b) lds[row_word(r * MA + b, tid)] = xr[cx_bitrev(b, LA)];
+        }
+    }
+    // phase B: row = tid >> 5, lanes over the low five bits of the column
+    static TOYNI_HD void phaseB(uint32_t tid, uint32_t* lds, const uint32_t* tw1) {
+        const uint32_t lo = tid & 31u, row = tid >> 5;
+        uint32_t x[E];
+        const uint32_t base = row * PITCH + lo;
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) x[i] = lds[base + i * 33u];
+        Pass<KIND_ROW_N, 5, 5, 3>::template stages<5, 5>(x, tw1, lo, nullptr);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) lds[base + i * 33u] = x[i];
+    }
+    // phase C: lanes over (k_a, low bits of k_b)
+    static TOYNI_HD void phaseC(const LdsArgs& g, uint64_t tile, uint32_t tid, const uint32_t* lds, const Uniform& uni) {
+        const uint32_t ka = tid & (MA - 1u), hi_rev = (tid >> LA) & 31u, r = tid >> (LA + 5);
+        const uint32_t hi = bitrev32(hi_rev, 5);
+        uint32_t x[E];
+        const uint32_t base = (r * MA + ka) * PITCH + hi * 33u;
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) x[i] = lds[base + i];
+        Pass<KIND_ROW_N, 5, 5, 3>::template stages<5, 0>(x, nullptr, 0u, uni.b);
+        const uint64_t b0 = tile * R;
+        if (b0 + r >= g.batch) return;
+        uint32_t* out = g.out + (b0 << LOG_N);
+        const uint32_t k0 = ka + (hi_rev << LA);                 // output index of b = 0; element b sits 32 * M_a further
+        const uint32_t off0 = ((r << LOG_N) + k0) << 2;
+        if (g.cs_mode == 2u) {                                   // inverse coset transform: X[k] *= s^k
+            uint32_t tw = mont_mul(g.cs_hi[k0 >> g.cs_lowbits], g.cs_lo[k0 & ((1u << g.cs_lowbits) - 1u)]);
+#pragma unroll
+            for (uint32_t b = 0; b < E; ++b) {
+                st32(out, off0 + ((b << (5 + LA)) << 2), mont_mul(x[cx_bitrev(b, 5)], tw));
+                if (b + 1 < E) { tw = mont_mul(tw, g.cs_g); TOYNI_PIN(tw); }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t b = 0; b < E; ++b) st32(out, off0 + ((b << (5 + LA)) << 2), x[cx_bitrev(b, 5)]);
+        }
+    }
+};
+
 // ---- u64 <-> u32 edge of the reference-shaped entry points (src/ntt.rs:233: &mut [BabyBear] as *mut u64) ----
 // narrow also reduces mod p, so a non-canonical u64 behaves like BabyBear::new (src/babybear.rs:26-30)
 TOYNI_HD uint32_t narrow_u64(uint64_t v) { return (uint32_t)(v % BB_P); }

@@ -33,6 +33,9 @@ struct NttPlan {
     // domain table: two-level w_n^x (fwd blob) / w_n^-x (inv blob), x < n
     uint32_t dom_lo_off = 0, dom_hi_off = 0, dom_lowbits = 0;
     uint32_t scale_inv = 0;             // Montgomery form of n^-1, applied by the first pass of an inverse transform
+    // n = 2^11 .. 2^15: tables of the single-sweep LDS-resident kernel (LdsPass<lds_la>); lds_la = 0 otherwise
+    int lds_la = 0;
+    uint32_t lds_stage_a_off = 0, lds_stage_b_off = 0, lds_gtab_off = 0;
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
 
@@ -109,6 +112,16 @@ inline bool build_plan(int log_n, NttPlan& plan) {
             }
             if (dir == 0) { pp.stage_off = stage_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
             consumed += pp.log_m;
+        }
+        if (log_n >= 11 && log_n <= 15) {
+            plan.lds_la = log_n - 10;
+            plan.lds_stage_a_off = (uint32_t)blob.size();
+            append_stage_table(blob, plan.lds_la, bb_pow_host(w, 1ull << 10));            // w_{M_a} = w_n^1024
+            plan.lds_stage_b_off = (uint32_t)blob.size();
+            append_stage_table(blob, 10, bb_pow_host(w, 1ull << plan.lds_la));           // w_1024 = w_n^{M_a}
+            plan.lds_gtab_off = (uint32_t)blob.size();
+            uint32_t cur = 1;
+            for (uint32_t j = 0; j < 1024; ++j) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, w); }
         }
         // domain table w_n^(+-x), x < n: the FRI fold reads the inverse one (x_i^-1 = x0^-1 * w_n^-i), the
         // multi-GPU 4-step transform both (same offsets in both blobs)
@@ -267,6 +280,39 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         if (!ok) return false;
     }
     return true;
+}
+
+// Arguments of the single-sweep kernel for plans that have one (plan.lds_la != 0).  launch(LdsPass<LA>{}, args, ntiles).
+template <class Launch>
+inline bool lds_transform(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src, uint32_t* dst, uint64_t batch,
+                          Launch&& launch, const CosetTables& cs = CosetTables()) {
+    if (!plan.lds_la) return false;
+    if (batch == 0) return true;
+    LdsArgs g{};
+    g.in = src;
+    g.out = dst;
+    g.stage_a = tables + plan.lds_stage_a_off;
+    g.stage_b = tables + plan.lds_stage_b_off;
+    g.gtab = tables + plan.lds_gtab_off;
+    g.scale = inverse ? plan.scale_inv : 0u;
+    g.batch = batch;
+    if (cs.lo) {
+        g.cs_lo = cs.lo;
+        g.cs_hi = cs.hi;
+        g.cs_lowbits = cs.lowbits;
+        g.cs_mode = inverse ? 2u : 1u;
+        g.cs_g = to_mont_host(bb_pow_host(cs.s, inverse ? (32ull << plan.lds_la) : 1024ull));
+    }
+    const uint64_t per_tile = 32u >> plan.lds_la;
+    const uint64_t ntiles = (batch + per_tile - 1) / per_tile;
+    switch (plan.lds_la) {
+        case 1: launch(LdsPass<1>{}, g, ntiles); return true;
+        case 2: launch(LdsPass<2>{}, g, ntiles); return true;
+        case 3: launch(LdsPass<3>{}, g, ntiles); return true;
+        case 4: launch(LdsPass<4>{}, g, ntiles); return true;
+        case 5: launch(LdsPass<5>{}, g, ntiles); return true;
+    }
+    return false;
 }
 
 // ---- one transform split over several devices (toyni_hip.h, section 2b) --------------------------------

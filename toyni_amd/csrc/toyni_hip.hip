@@ -100,6 +100,49 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
     }
 }
 
+// Single-sweep transform for n = 2^11 .. 2^15 (LdsPass, ntt_kernels.hpp): one 1024-thread workgroup per CU keeps a tile of
+// 32 rows x 1024 words in LDS through all three phases; persistent over the tiles of the batch.  The next tile's loads
+// are issued as soon as phase A has parked the registers in LDS, ahead of this tile's stores (vmcnt retires in issue
+// order, see above); a tile that has a successor is never ragged, so exactly E stores follow every prefetch.
+template <class L>
+__global__ void __launch_bounds__(L::T, 4) ntt_lds_kernel(const LdsArgs g, const uint32_t ntiles) {
+    __shared__ uint32_t lds[L::LDS_WORDS + L::TW1_WORDS];
+    const uint32_t tid = threadIdx.x;
+    uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    uint32_t* lds_tw1 = lds + L::LDS_WORDS;
+    uint32_t x[L::E];
+    L::loadA(g, tile, tid, x);
+    const typename L::Seeds seeds = L::seedsA(g, tid);
+    const typename L::Uniform uni = L::load_uniform(g);
+    for (uint32_t j = tid; j < L::TW1_WORDS; j += L::T) lds_tw1[j] = L::tw1_global(g)[j];
+    TOYNI_WAIT_VMEM0();
+    __syncthreads();
+    while (true) {
+        TOYNI_WAIT_VMEM_ALLOW(L::E);  // the tile's loads were issued before the previous tile's E stores
+        L::phaseA(g, tid, x, seeds, uni, lds);
+        TOYNI_SCHED_FENCE();
+        const uint32_t next = tile + gridDim.x;
+        const bool more = next < ntiles;  // uniform
+        if (more) L::loadA(g, next, tid, x);  // prefetch
+        TOYNI_SCHED_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        TOYNI_SCHED_FENCE();
+        L::phaseB(tid, lds, lds_tw1);
+        TOYNI_SCHED_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        TOYNI_SCHED_FENCE();
+        L::phaseC(g, tile, tid, lds, uni);
+        if (!more) break;
+        TOYNI_SCHED_FENCE();
+        __builtin_amdgcn_s_barrier();  // phase C's LDS reads are in registers before the tile is overwritten
+        TOYNI_SCHED_FENCE();
+        tile = next;
+    }
+}
+
 __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = narrow_u64(in[i]);
@@ -416,6 +459,12 @@ int prefetch_depth() {
     return depth;
 }
 
+// TOYNI_NO_LDS_KERNEL=1: run n = 2^11 .. 2^15 through the two-pass plan instead of the single-sweep kernel (A/B knob)
+bool lds_kernel_enabled() {
+    static const bool on = [] { const char* env = std::getenv("TOYNI_NO_LDS_KERNEL"); return !(env && env[0] == '1'); }();
+    return on;
+}
+
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
     if constexpr (LZ > 0) {  // low-degree-extension first pass: one variant (the prefetch knob applies to the whole-input kernels)
@@ -465,6 +514,29 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     if (c->plan.log_n == 0) {
         if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         return 0;
+    }
+    if (c->plan.lds_la && lde_log == 0 && lds_kernel_enabled()) {
+        // n = 2^11 .. 2^15: one sweep, the transform never leaves the workgroup's LDS (no intermediate buffer)
+        hipError_t err = hipSuccess;
+        const bool ok = lds_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch,
+                                      [&](auto pass, const LdsArgs& g, uint64_t ntiles) {
+                                          using L = decltype(pass);
+                                          toyni_ntt_ctx::TimingRec rec{nullptr, nullptr, inverse ? 1 : 0, 0};
+                                          if (c->timing) {
+                                              if ((err = hipEventCreate(&rec.e0)) != hipSuccess) return;
+                                              if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
+                                              (void)hipEventRecord(rec.e0, s);
+                                          }
+                                          const uint64_t grid = ntiles < (uint64_t)c->num_cus ? ntiles : (uint64_t)c->num_cus;  // one workgroup per CU (LDS)
+                                          hipLaunchKernelGGL((ntt_lds_kernel<L>), dim3((unsigned)grid), dim3(L::T), 0, s, g, (uint32_t)ntiles);
+                                          err = hipGetLastError();
+                                          if (c->timing) {
+                                              (void)hipEventRecord(rec.e1, s);
+                                              c->timing_recs.push_back(rec);
+                                          }
+                                      }, cs);
+        if (!ok) return TOYNI_E_INVALID_SIZE;
+        return (int)err;
     }
     size_t chunk = batch;
     if (c->chunk_elems && c->plan.npasses > 1) {
@@ -605,7 +677,11 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
 
 uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
-int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
+int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) {
+    if (!c) return -1;
+    if (c->plan.log_n == 0) return 0;
+    return (c->plan.lds_la && lds_kernel_enabled()) ? 1 : c->plan.npasses;
+}
 
 int toyni_ntt_ctx_timing(toyni_ntt_ctx* c, int enable) {
     if (!c) return TOYNI_E_NULL;
