@@ -61,7 +61,8 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out);
 int toyni_ntt_ctx_destroy(toyni_ntt_ctx* ctx);
 uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* ctx);
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* ctx);
-int toyni_ntt_ctx_passes(const toyni_ntt_ctx* ctx);     /* HBM sweeps per transform (1..3) */
+int toyni_ntt_ctx_passes(const toyni_ntt_ctx* ctx);     /* HBM sweeps per transform of the context's plan (1..3); large batches
+                                                          * of n = 2^11..2^13 run a single-sweep kernel instead of their 2 passes */
 /* Multi-pass transforms of a large batch are issued in chunks of about chunk_elems elements so that the
  * intermediate buffer stays cache-resident; 0 = whole batch at once (also env TOYNI_CHUNK_ELEMS). */
 int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);

@@ -38,6 +38,7 @@ using namespace toyni;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
+static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
                           int lde_log = 0) {
@@ -69,7 +70,7 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
                 for (uint32_t tid = 0; tid < L::T; ++tid) L::phaseB(tid, lds.data(), L::tw1_global(g));
                 for (uint32_t tid = 0; tid < L::T; ++tid) L::phaseC(g, tile, tid, lds.data(), L::load_uniform(g));
             }
-        }, cs);
+        }, cs, lds_rows);
         CHECK(okl, "lds transform rejected log_n=%d", plan.log_n);
         return;
     }
@@ -353,8 +354,12 @@ int main(int argc, char** argv) {
             use_lds = false;
             test_ntt(log_n, 3, 0);
             test_coset(log_n, 2, 7);
-            use_lds = true;                         // ... then (below) the single-sweep kernel, incl. ragged tiles
-            test_ntt(log_n, (32u >> (log_n - 10)) + 1, 0);
+            use_lds = true;                         // ... then the single-sweep kernel in every workgroup shape, incl. ragged tiles
+            for (lds_rows = 3; lds_rows <= 5; ++lds_rows) {
+                test_ntt(log_n, ((1u << lds_rows) >> (log_n - 10)) + 1, 0);
+                test_coset(log_n, 3, 7);
+            }
+            lds_rows = 5;
         }
         test_ntt(log_n, 1, 0);
         test_ntt(log_n, log_n <= 10 ? 70 : 3, 0);   // ragged row tiles for the single-pass kinds

@@ -585,31 +585,67 @@ def test_slab_entry_points_reject_bad_shapes(ta):
     buf.free()
 
 
-def test_two_pass_plan_of_the_single_sweep_sizes(ta):
-    # n = 2^11 .. 2^15 normally run the single-sweep LDS kernel; their two-pass plan (whose first pass the LDE and slab
-    # entry points use) stays selectable with TOYNI_NO_LDS_KERNEL=1 -- checked in a child process (the knob is read once)
+def test_both_executors_of_the_single_sweep_sizes(ta):
+    # n = 2^11 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
+    # batches of 2^11 .. 2^13 only).  Force each one for every size, small ragged batches, in child processes (the knobs are
+    # read once per process); which executor ran is read off the launch records (1 launch per transform vs 2).
     import os
     import subprocess
     import sys
     code = (
-        "import numpy as np, oracle, toyni_amd\n"
-        "from test_gpu_parity import dev_transform\n"
+        "import os, numpy as np, oracle, toyni_amd\n"
+        "from test_gpu_parity import DevBuf\n"
+        "want_launches = int(os.environ['TOYNI_TEST_LAUNCHES'])\n"
         "for log_n in range(11, 16):\n"
-        "    n = 1 << log_n\n"
-        "    assert toyni_amd.NttContext(n).passes == 2\n"
-        "    x = oracle.splitmix(3 * n, 777 + log_n).astype(np.uint32)\n"
-        "    f = dev_transform(toyni_amd, x, n, 3, False)\n"
-        "    i = dev_transform(toyni_amd, x, n, 3, True, shift=7)\n"
-        "    for b in range(3):\n"
+        "    n, batch = 1 << log_n, 5\n"
+        "    ctx = toyni_amd.NttContext(n)\n"
+        "    x = oracle.splitmix(batch * n, 777 + log_n).astype(np.uint32)\n"
+        "    a, o = DevBuf(toyni_amd, x.nbytes), DevBuf(toyni_amd, x.nbytes)\n"
+        "    a.upload(x)\n"
+        "    ctx.timing(True)\n"
+        "    ctx.run_device(a.ptr, o.ptr, batch, False)\n"
+        "    t = ctx.read_timing()\n"
+        "    assert sum(t['launches']['forward']) == want_launches, (log_n, t['launches'])\n"
+        "    f = o.download(np.uint32, x.size)\n"
+        "    ctx.run_device(a.ptr, a.ptr, batch, True, shift=7)\n"
+        "    ctx.synchronize()\n"
+        "    i = a.download(np.uint32, x.size)\n"
+        "    for b in range(batch):\n"
         "        row = x[b * n:(b + 1) * n].astype(np.uint64)\n"
         "        assert (f[b * n:(b + 1) * n] == oracle.ntt(row)).all()\n"
         "        assert (i[b * n:(b + 1) * n] == oracle.domain_ifft(row, 7)).all()\n"
-        "print('TWO PASS OK')\n")
+        "print('EXECUTOR OK')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TOYNI_NO_LDS_KERNEL="1", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests")]))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
-    assert res.returncode == 0 and "TWO PASS OK" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
-    assert ta.NttContext(1 << 13).passes == 1                       # this process: the single-sweep kernel
+    pp = os.pathsep.join([root, os.path.join(root, "tests")])
+    modes = [("two-pass", {"TOYNI_NO_LDS_KERNEL": "1", "TOYNI_TEST_LAUNCHES": "2"}),
+             ("sweep, 4 workgroups per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_TEST_LAUNCHES": "1"}),
+             ("sweep, 1 workgroup per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_LDS_ROWS": "5", "TOYNI_TEST_LAUNCHES": "1"})]
+    for mode, extra in modes:
+        env = dict(os.environ, PYTHONPATH=pp, **extra)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert res.returncode == 0 and "EXECUTOR OK" in res.stdout, mode + ": " + res.stdout[-1000:] + res.stderr[-3000:]
+
+
+def test_large_batches_of_mid_sizes_take_the_single_sweep_kernel(ta):
+    # the default policy: >= 2^25 elements of n = 2^11 .. 2^13 per call -> one launch; checked against the oracle on sampled rows
+    n, batch = 1 << 12, 1 << 13
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+    ctx = ta.NttContext(n)
+    buf = DevBuf(ta, x.nbytes)
+    buf.upload(x)
+    ctx.timing(True)
+    ctx.run_device(buf.ptr, buf.ptr, batch, False)
+    assert ctx.read_timing()["launches"]["forward"] == [1, 0]
+    ctx.timing(False)
+    got = buf.download(np.uint32, x.size)
+    for b in (0, 1, 7, 4095, 4096, batch - 1):
+        assert (got[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n].astype(np.uint64))).all(), b
+    ctx.run_device(buf.ptr, buf.ptr, batch, True)
+    ctx.synchronize()
+    assert (buf.download(np.uint32, x.size) == x).all()
+    buf.free()
+    ctx.destroy()
 
 
 # ---------------------------------------------------------------- low-degree extension (src/fibonacci.rs:101-103)

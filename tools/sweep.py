@@ -21,21 +21,21 @@ def main():
     lo, hi = (int(v) for v in os.environ.get("SWEEP_RANGE", "4:28").split(":"))
     for log_n in range(lo, hi):
         n = 1 << log_n
-        batch = TOTAL // n
+        batch = int(os.environ.get("SWEEP_BATCH", TOTAL // n))   # SWEEP_BATCH=1: latency of one transform
         ctx = toyni_amd.NttContext(n)
         f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
         f(); f()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
+        reps = 5 if batch > 1 else 200
         a.record()
         for _ in range(reps):
             f()
         b.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
-        print(f"n=2^{log_n:<2d} batch={batch:<9d} passes={ctx.passes} {ms:8.3f} ms  {TOTAL / ms / 1e6:8.1f} Gelem/s  "
-              f"{8.0 * ctx.passes * TOTAL / ms / 1e9:7.2f} TB/s moved", flush=True)
+        print(f"n=2^{log_n:<2d} batch={batch:<9d} passes={ctx.passes} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
+              f"{8.0 * ctx.passes * batch * n / ms / 1e9:7.2f} TB/s moved", flush=True)
         ctx.destroy()
 
 

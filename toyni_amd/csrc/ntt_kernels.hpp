@@ -506,9 +506,9 @@ struct Pass {
 };
 
 // ---- single-sweep transforms for n = 2^11 .. 2^15: the whole transform stays in one workgroup's LDS ----
-// n = M_a * 1024 with M_a = 2^LA (LA = 1..5).  A tile is R = 32 / M_a consecutive transforms of the batch = 32 rows of
-// 1024 words = one contiguous 128 KiB block of HBM, read once and written once (the two-pass plan moves it twice).
-//   phase A  thread <-> column j' (= tid, 4-KiB coalesced rows): the M_a-point transforms over j_a for every transform of
+// n = M_a * 1024 with M_a = 2^LA (LA = 1..5).  A tile is R = ROWS / M_a consecutive transforms of the batch = ROWS rows of
+// 1024 words = one contiguous block of HBM, read once and written once (the two-pass plan moves it twice).
+//   phase A  thread <-> columns j' (= tid + c T, 4-KiB coalesced rows): the M_a-point transforms over j_a for every transform of
 //            the tile, in registers, uniform twiddles; times w_n^(j' k_a) (running product of the thread's own w_n^j');
 //            row (r, k_a) of the tile is parked in LDS
 //   phase B  the 1024-point row transforms, high five stage bits (per-thread twiddles), in place in LDS
@@ -534,15 +534,19 @@ struct LdsArgs {
     uint32_t cs_g;
 };
 
-template <int LA>
+template <int LA, int LROWS = 5>
 struct LdsPass {
-    static_assert(LA >= 1 && LA <= 5, "n = 2^11 .. 2^15");
+    static_assert(LA >= 1 && LA <= 5 && LROWS >= LA && LROWS <= 5, "n = 2^11 .. 2^15; a tile holds at least one transform");
+    // ROWS rows of 1024 words per workgroup: 32 = one 1024-thread workgroup per CU; 16 / 8 = two / four smaller workgroups
+    // per CU that drift apart, so one computes while another sits at a barrier or an LDS burst (same waves per CU).
     static constexpr int LOG_N = LA + 10;
-    static constexpr uint32_t MA = 1u << LA, R = 32u >> LA, T = 1024u, E = 32u;
+    static constexpr uint32_t MA = 1u << LA, ROWS = 1u << LROWS, R = ROWS >> LA, T = ROWS * 32u, E = 32u;
+    static constexpr uint32_t NCOL = 1024u / T;                 // columns per thread in phase A (= 32 / ROWS)
     static constexpr uint32_t PITCH = 32u * 33u + 1u;           // 1057 = 1 mod 32
-    static constexpr uint32_t LDS_WORDS = 32u * PITCH;
+    static constexpr uint32_t LDS_WORDS = ROWS * PITCH;
     static constexpr uint32_t TW1_WORDS = 1024u - 32u;          // stages 5..9 of the 1024-point stage table
     static constexpr uint32_t NU = 16u;                         // uniform twiddles of a 32-point step
+    static constexpr uint32_t WG_PER_CU = 32u / ROWS;
     struct Uniform { uint32_t a[MA > 1 ? MA / 2 : 1]; uint32_t b[NU]; };
 
     static TOYNI_HD Uniform load_uniform(const LdsArgs& g) {
@@ -556,49 +560,60 @@ struct LdsPass {
     static TOYNI_HD const uint32_t* tw1_global(const LdsArgs& g) { return g.stage_b + 31u; }
     static TOYNI_HD uint32_t row_word(uint32_t row, uint32_t col) { return row * PITCH + (col >> 5) * 33u + (col & 31u); }
 
-    // phase A, loads: register r * MA + j_a = x_r[j_a * 1024 + j'] (zero for transforms beyond the batch)
+    // phase A, loads: register (c * R + r) * MA + j_a = x_r[j_a * 1024 + j'], j' = tid + c * T (zero beyond the batch)
     static TOYNI_HD void loadA(const LdsArgs& g, uint64_t tile, uint32_t tid, uint32_t (&x)[E]) {
         const uint64_t b0 = tile * R;
         const uint32_t* base = g.in + (b0 << LOG_N);
 #pragma unroll
-        for (uint32_t r = 0; r < R; ++r) {
-            const bool live = b0 + r < g.batch;   // uniform
+        for (uint32_t c = 0; c < NCOL; ++c) {
 #pragma unroll
-            for (uint32_t ja = 0; ja < MA; ++ja)
-                x[r * MA + ja] = live ? ld32(base, ((r << LOG_N) + (ja << 10) + tid) << 2) : 0u;
+            for (uint32_t r = 0; r < R; ++r) {
+                const bool live = b0 + r < g.batch;   // uniform
+#pragma unroll
+                for (uint32_t ja = 0; ja < MA; ++ja)
+                    x[(c * R + r) * MA + ja] = live ? ld32(base, ((r << LOG_N) + (ja << 10) + tid + c * T) << 2) : 0u;
+            }
         }
     }
-    // the thread's own constants: w_n^j' and (forward coset transform) s^j'
-    struct Seeds { uint32_t g, cs_a; };
+    // the thread's own constants: w_n^j' and (forward coset transform) s^j' for each of its columns
+    struct Seeds { uint32_t g[NCOL], cs_a[NCOL]; };
     static TOYNI_HD Seeds seedsA(const LdsArgs& g, uint32_t tid) {
-        Seeds s{g.gtab[tid], 0u};
-        if (g.cs_mode == 1u) s.cs_a = mont_mul(g.cs_hi[tid >> g.cs_lowbits], g.cs_lo[tid & ((1u << g.cs_lowbits) - 1u)]);
+        Seeds s;
+#pragma unroll
+        for (uint32_t c = 0; c < NCOL; ++c) {
+            const uint32_t j = tid + c * T;
+            s.g[c] = g.gtab[j];
+            s.cs_a[c] = g.cs_mode == 1u ? mont_mul(g.cs_hi[j >> g.cs_lowbits], g.cs_lo[j & ((1u << g.cs_lowbits) - 1u)]) : 0u;
+        }
         return s;
     }
     static TOYNI_HD void phaseA(const LdsArgs& g, uint32_t tid, uint32_t (&x)[E], const Seeds& sd, const Uniform& uni, uint32_t* lds) {
 #pragma unroll
-        for (uint32_t r = 0; r < R; ++r) {
-            uint32_t (&xr)[MA] = *reinterpret_cast<uint32_t (*)[MA]>(&x[r * MA]);
-            if (g.cs_mode == 1u) {   // x[j] *= s^j, j = j_a * 1024 + j'
-                uint32_t tw = sd.cs_a;
+        for (uint32_t c = 0; c < NCOL; ++c) {
 #pragma unroll
-                for (uint32_t ja = 0; ja < MA; ++ja) {
-                    xr[ja] = mont_mul(xr[ja], tw);
-                    if (ja + 1 < MA) { tw = mont_mul(tw, g.cs_g); TOYNI_PIN(tw); }
+            for (uint32_t r = 0; r < R; ++r) {
+                uint32_t (&xr)[MA] = *reinterpret_cast<uint32_t (*)[MA]>(&x[(c * R + r) * MA]);
+                if (g.cs_mode == 1u) {   // x[j] *= s^j, j = j_a * 1024 + j'
+                    uint32_t tw = sd.cs_a[c];
+#pragma unroll
+                    for (uint32_t ja = 0; ja < MA; ++ja) {
+                        xr[ja] = mont_mul(xr[ja], tw);
+                        if (ja + 1 < MA) { tw = mont_mul(tw, g.cs_g); TOYNI_PIN(tw); }
+                    }
                 }
-            }
-            Pass<KIND_ROW_N, 5, 5, 3>::template stages<LA, 0>(xr, nullptr, 0u, uni.a);
-            // times w_n^(j' k_a) (and n^-1 on an inverse): k_a = b sits in register bitrev(b)
-            uint32_t tw = g.scale ? g.scale : BB_MONT_ONE;
-            if (g.scale) xr[0] = mont_mul(xr[0], tw);
+                Pass<KIND_ROW_N, 5, 5, 3>::template stages<LA, 0>(xr, nullptr, 0u, uni.a);
+                // times w_n^(j' k_a) (and n^-1 on an inverse): k_a = b sits in register bitrev(b)
+                uint32_t tw = g.scale ? g.scale : BB_MONT_ONE;
+                if (g.scale) xr[0] = mont_mul(xr[0], tw);
 #pragma unroll
-            for (uint32_t b = 1; b < MA; ++b) {
-                tw = mont_mul(tw, sd.g);
-                TOYNI_PIN(tw);
-                xr[cx_bitrev(b, LA)] = mont_mul(xr[cx_bitrev(b, LA)], tw);
-            }
+                for (uint32_t b = 1; b < MA; ++b) {
+                    tw = mont_mul(tw, sd.g[c]);
+                    TOYNI_PIN(tw);
+                    xr[cx_bitrev(b, LA)] = mont_mul(xr[cx_bitrev(b, LA)], tw);
+                }
 #pragma unroll
-            for (uint32_t b = 0; b < MA; ++b) lds[row_word(r * MA + b, tid)] = xr[cx_bitrev(b, LA)];
+                for (uint32_t b = 0; b < MA; ++b) lds[row_word(r * MA + b, tid + c * T)] = xr[cx_bitrev(b, LA)];
+            }
         }
     }
     // phase B: row = tid >> 5, lanes over the low five bits of the column

@@ -285,7 +285,7 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
 // Arguments of the single-sweep kernel for plans that have one (plan.lds_la != 0).  launch(LdsPass<LA>{}, args, ntiles).
 template <class Launch>
 inline bool lds_transform(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src, uint32_t* dst, uint64_t batch,
-                          Launch&& launch, const CosetTables& cs = CosetTables()) {
+                          Launch&& launch, const CosetTables& cs = CosetTables(), int log_rows = 5) {
     if (!plan.lds_la) return false;
     if (batch == 0) return true;
     LdsArgs g{};
@@ -303,15 +303,17 @@ inline bool lds_transform(const NttPlan& plan, const uint32_t* tables, bool inve
         g.cs_mode = inverse ? 2u : 1u;
         g.cs_g = to_mont_host(bb_pow_host(cs.s, inverse ? (32ull << plan.lds_la) : 1024ull));
     }
-    const uint64_t per_tile = 32u >> plan.lds_la;
+    // rows per workgroup: 2^log_rows (32 = one workgroup per CU; 16 / 8 = two / four decoupled ones), at least one transform
+    if (log_rows > 5) log_rows = 5;
+    if (log_rows < 3) log_rows = 3;
+    if (log_rows < plan.lds_la) log_rows = plan.lds_la;
+    const uint64_t per_tile = (1u << log_rows) >> plan.lds_la;
     const uint64_t ntiles = (batch + per_tile - 1) / per_tile;
-    switch (plan.lds_la) {
-        case 1: launch(LdsPass<1>{}, g, ntiles); return true;
-        case 2: launch(LdsPass<2>{}, g, ntiles); return true;
-        case 3: launch(LdsPass<3>{}, g, ntiles); return true;
-        case 4: launch(LdsPass<4>{}, g, ntiles); return true;
-        case 5: launch(LdsPass<5>{}, g, ntiles); return true;
-    }
+#define TOYNI_LDS_CASE(A, B) if (plan.lds_la == A && log_rows == B) { launch(LdsPass<A, B>{}, g, ntiles); return true; }
+    TOYNI_LDS_CASE(1, 5) TOYNI_LDS_CASE(2, 5) TOYNI_LDS_CASE(3, 5) TOYNI_LDS_CASE(4, 5) TOYNI_LDS_CASE(5, 5)
+    TOYNI_LDS_CASE(1, 4) TOYNI_LDS_CASE(2, 4) TOYNI_LDS_CASE(3, 4) TOYNI_LDS_CASE(4, 4)
+    TOYNI_LDS_CASE(1, 3) TOYNI_LDS_CASE(2, 3) TOYNI_LDS_CASE(3, 3)
+#undef TOYNI_LDS_CASE
     return false;
 }
 

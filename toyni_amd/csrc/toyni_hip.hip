@@ -459,10 +459,35 @@ int prefetch_depth() {
     return depth;
 }
 
-// TOYNI_NO_LDS_KERNEL=1: run n = 2^11 .. 2^15 through the two-pass plan instead of the single-sweep kernel (A/B knob)
-bool lds_kernel_enabled() {
-    static const bool on = [] { const char* env = std::getenv("TOYNI_NO_LDS_KERNEL"); return !(env && env[0] == '1'); }();
-    return on;
+// When the single-sweep kernel runs instead of the two-pass plan: sizes 2^11 .. 2^TOYNI_LDS_MAX_LOG (default 13; 10 = never,
+// 15 = every size it exists for) and launches of at least TOYNI_LDS_MIN_ELEMS elements (default 2^25).  Measured
+// (profiles/r01_sweep_lds.txt): it halves the HBM traffic and is 5-19 % faster on large batches of 2^11 .. 2^13, but the sweep is
+// VALU-bound where the two-pass plan is HBM-bound, so from 2^14 on the two-pass plan wins; and a lone transform is one
+// 256-thread workgroup's serial work here (7.7-9.6 us) against two launches of many small workgroups (5.6-6.8 us).
+int lds_max_log() {
+    static const int v = [] {
+        if (const char* off = std::getenv("TOYNI_NO_LDS_KERNEL")) if (off[0] == '1') return 10;
+        const char* env = std::getenv("TOYNI_LDS_MAX_LOG");
+        return env ? std::atoi(env) : 13;
+    }();
+    return v;
+}
+uint64_t lds_min_elems() {
+    static const uint64_t v = [] {
+        const char* env = std::getenv("TOYNI_LDS_MIN_ELEMS");
+        return env ? (uint64_t)std::strtoull(env, nullptr, 0) : (uint64_t)1 << 25;
+    }();
+    return v;
+}
+bool lds_kernel_enabled(const NttPlan& plan, uint64_t batch) {
+    return plan.lds_la != 0 && plan.log_n <= lds_max_log() && (batch << plan.log_n) >= lds_min_elems();
+}
+
+// rows per workgroup of the single-sweep kernel, as a power of two (TOYNI_LDS_ROWS = 3 | 4 | 5; tuning knob; 8 rows =
+// four 256-thread workgroups per CU measured best)
+int lds_log_rows() {
+    static const int v = [] { const char* env = std::getenv("TOYNI_LDS_ROWS"); return env ? std::atoi(env) : 3; }();
+    return v;
 }
 
 template <class P, int LZ = 0>
@@ -515,7 +540,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    if (c->plan.lds_la && lde_log == 0 && lds_kernel_enabled()) {
+    if (lde_log == 0 && lds_kernel_enabled(c->plan, batch)) {
         // n = 2^11 .. 2^15: one sweep, the transform never leaves the workgroup's LDS (no intermediate buffer)
         hipError_t err = hipSuccess;
         const bool ok = lds_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch,
@@ -527,14 +552,15 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                               if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
                                               (void)hipEventRecord(rec.e0, s);
                                           }
-                                          const uint64_t grid = ntiles < (uint64_t)c->num_cus ? ntiles : (uint64_t)c->num_cus;  // one workgroup per CU (LDS)
+                                          uint64_t grid = (uint64_t)c->num_cus * L::WG_PER_CU;  // as many workgroups as the LDS of a CU holds
+                                          if (grid > ntiles) grid = ntiles;
                                           hipLaunchKernelGGL((ntt_lds_kernel<L>), dim3((unsigned)grid), dim3(L::T), 0, s, g, (uint32_t)ntiles);
                                           err = hipGetLastError();
                                           if (c->timing) {
                                               (void)hipEventRecord(rec.e1, s);
                                               c->timing_recs.push_back(rec);
                                           }
-                                      }, cs);
+                                      }, cs, lds_log_rows());
         if (!ok) return TOYNI_E_INVALID_SIZE;
         return (int)err;
     }
@@ -677,11 +703,7 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
 
 uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
-int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) {
-    if (!c) return -1;
-    if (c->plan.log_n == 0) return 0;
-    return (c->plan.lds_la && lds_kernel_enabled()) ? 1 : c->plan.npasses;
-}
+int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
 
 int toyni_ntt_ctx_timing(toyni_ntt_ctx* c, int enable) {
     if (!c) return TOYNI_E_NULL;
