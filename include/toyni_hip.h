@@ -138,6 +138,11 @@ int toyni_ntt_slab_pass_device(toyni_ntt_ctx* ctx, uint32_t* d_slab, size_t cols
 int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
                                    size_t parts, int inverse, void* stream);
 
+/* Domain points on the device: d_out[i] = shift * w_m^i, i < m (roots_of_unity_domain, src/ntt.rs:69-81, with shift = 1;
+ * BabyBearDomain::elements, src/math/domain.rs:61-69) -- the xs that fri_fold and the prover's pointwise steps consume.
+ * m: power of two <= the context's n.  The reference's serial multiply chain becomes independent table lookups. */
+int toyni_domain_elements_device(toyni_ntt_ctx* ctx, uint32_t* d_out, size_t m, uint32_t shift, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 3. FRI pairwise fold (net-new on the device; oracle src/math/fri.rs:27-48)
  *    out[i] = (a + b)/2 + (a - b)/2 * beta / x_i,  a = evals[i], b = evals[i + m/2],  i < m/2

@@ -218,10 +218,9 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     trace_commitment = trace_tree.root()
     lap("1_interpolate_mask_lde_commit")
 
-    # x_i = 7 w_N^i: the coset FFT of the polynomial "x"
-    xs32 = torch.zeros(N, dtype=torch.int32, device=dev)
-    xs32[1] = 1
-    ntt_dev(ctx_N, xs32, False, shift=COSET_SHIFT)
+    # x_i = 7 w_N^i
+    xs32 = torch.empty(N, dtype=torch.int32, device=dev)
+    ctx_N.domain_elements_device(xs32.data_ptr(), N, COSET_SHIFT, stream=stream)   # lde_domain.elements(), src/fibonacci.rs:133
     xs = xs32.to(torch.int64)
 
     # ---- 2. constraint & quotient (src/fibonacci.rs:133-153) ----

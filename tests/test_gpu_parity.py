@@ -705,6 +705,21 @@ def test_lde_rejects_bad_arguments(ta):
     buf.free()
 
 
+@pytest.mark.parametrize("log_ctx,log_m,shift", [(0, 0, 1), (4, 4, 1), (10, 3, 7), (16, 16, 7), (21, 21, 7), (21, 12, 1234567), (27, 20, 7)])
+def test_domain_elements_match_reference_chain(ta, log_ctx, log_m, shift):
+    # roots_of_unity_domain (src/ntt.rs:69-81) / BabyBearDomain::elements (src/math/domain.rs:61-69)
+    ctx = ta.ntt.get_or_create_ctx(1 << log_ctx)
+    m = 1 << log_m
+    buf = DevBuf(ta, 4 * m)
+    ctx.domain_elements_device(buf.ptr, m, shift)
+    ctx.synchronize()
+    got = buf.download(np.uint32, m)
+    buf.free()
+    assert (got.astype(np.uint64) == oracle.domain_elements(m, shift)).all()
+    if shift == 1:
+        assert (got.astype(np.uint64) == oracle.roots_of_unity_domain(m)).all()
+
+
 def test_in_workload_launch_timing(ta):
     # toyni_ntt_ctx_timing: every pass launch between enable and read is bracketed by events; results are untouched
     n, batch = 1 << 16, 8

@@ -203,6 +203,19 @@ __global__ void __launch_bounds__(256) slab_relayout_kernel(const RelayoutArgs a
     }
 }
 
+// roots_of_unity_domain / BabyBearDomain::elements (src/ntt.rs:69-81, src/math/domain.rs:61-69): out[i] = shift * w_m^i, the
+// reference's serial multiply chain as independent two-level table lookups (w_m^i = w_n^(i << log_step), forward domain table)
+__global__ void __launch_bounds__(256) domain_elements_kernel(uint32_t* __restrict__ out, uint64_t m, uint32_t log_step, uint32_t shift,
+                                                               const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t lowbits) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lmask = (1u << lowbits) - 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const uint32_t e = (uint32_t)(i << log_step);
+        // mont_mul(hi, lo) = Montgomery form of w^e; times the PLAIN shift leaves the plain product shift * w^e
+        out[i] = mont_mul(mont_mul(hi[e >> lowbits], lo[e & lmask]), shift);
+    }
+}
+
 // FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows
 __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
     const uint64_t half = f.half;
@@ -991,6 +1004,19 @@ int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint3
     a.lowbits = c->plan.dom_lowbits;
     const uint64_t quads = ((uint64_t)rows_local * s1) / 4;
     hipLaunchKernelGGL(slab_relayout_kernel, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, a, quads);
+    return (int)hipGetLastError();
+}
+
+// ---- domain points (the xs of fri_fold, the evaluation points of the prover) ----
+int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, uint32_t shift, void* stream) {
+    if (!c || !d_out) return TOYNI_E_NULL;
+    if (m == 0) return TOYNI_OK;
+    if (!is_pow2(m) || m > c->n || shift >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(domain_elements_kernel, dim3(grid_for(m)), dim3(256), 0, (hipStream_t)stream, d_out, (uint64_t)m,
+                       (uint32_t)(c->plan.log_n - ilog2(m)), shift, c->d_fwd + c->plan.dom_lo_off, c->d_fwd + c->plan.dom_hi_off,
+                       c->plan.dom_lowbits);
     return (int)hipGetLastError();
 }
 

@@ -113,6 +113,10 @@ class NttContext:
         else:
             check(lib.toyni_coset_ntt_device(self.handle, d_in, d_out, batch, shift, int(inverse), stream or None), "GPU coset NTT failed")
 
+    def domain_elements_device(self, d_out: int, m: int, shift: int = 1, stream: int = 0) -> None:
+        """d_out[i] = shift * w_m^i (roots_of_unity_domain / BabyBearDomain::elements), packed u32, m <= n."""
+        check(lib.toyni_domain_elements_device(self.handle, d_out, m, shift, stream or None), "GPU domain elements failed")
+
     def lde_device(self, d_coeffs: int, d_out: int, batch: int, log_blowup: int, shift: int = 1, stream: int = 0) -> None:
         """Low-degree extension: forward coset transform of batch vectors of n >> log_blowup coefficients, zero padding implied."""
         check(lib.toyni_lde_device(self.handle, d_coeffs, d_out, batch, log_blowup, shift, stream or None), "GPU LDE failed")
