@@ -447,6 +447,43 @@ def test_batch_1024_x_2_20(ta):
     buf.free()
 
 
+@pytest.mark.parametrize("log_n,batch", [(20, 3072), (24, 160), (12, 1 << 20), (8, (1 << 24) + 3)])
+def test_batches_beyond_4_gib(ta, log_n, batch):
+    # sized for 288 GB: 10 - 12 GiB of packed residues in one call, so element indices pass 2^31 and byte offsets 2^32 in
+    # every kind of pass (2-pass, 3-pass, the single-sweep kernel, ragged single-pass row tiles); the same 2^24-element
+    # block is tiled through the buffer, so every position must reproduce the first block's transform
+    n = 1 << log_n
+    block_elems = 1 << 24
+    per_block = block_elems // n
+    xb = oracle.splitmix(block_elems, 95 + log_n).astype(np.uint32)
+    total = n * batch
+    buf = DevBuf(ta, total * 4)
+    off = 0
+    while off < total:
+        m = min(block_elems, total - off)
+        buf.upload(xb[:m], offset=off * 4)
+        off += m
+    ctx = ta.ntt.get_or_create_ctx(n)
+    ctx.run_device(buf.ptr, buf.ptr, batch, False)
+    ctx.synchronize()
+    first = buf.download(np.uint32, block_elems)
+    for b in (0, per_block // 2, per_block - 1):
+        assert (first[b * n:(b + 1) * n] == oracle.ntt(xb[b * n:(b + 1) * n].astype(np.uint64))).all()
+    nblocks = total // block_elems
+    for r in (129, nblocks - 1):                                  # positions beyond 2^31 elements / 2^33 bytes
+        assert nblocks > r >= 129 and r * block_elems > (1 << 31)
+        assert (buf.download(np.uint32, block_elems, offset=r * block_elems * 4) == first).all()
+    tail = total - nblocks * block_elems                          # the ragged end (last case)
+    if tail:
+        assert (buf.download(np.uint32, tail, offset=nblocks * block_elems * 4) == first[:tail]).all()
+    ctx.run_device(buf.ptr, buf.ptr, batch, True)
+    ctx.synchronize()
+    assert (buf.download(np.uint32, block_elems, offset=(nblocks - 1) * block_elems * 4) == xb).all()
+    if tail:
+        assert (buf.download(np.uint32, tail, offset=nblocks * block_elems * 4) == xb[:tail]).all()
+    buf.free()
+
+
 # ---------------------------------------------------------------- multi-GPU forms on one GPU (world = 1)
 @pytest.mark.parametrize("log_n", [10, 16, 22])
 def test_fourstep_world1_matches_oracle(ta, log_n):
