@@ -22,8 +22,9 @@ def test_kernel_bodies_match_oracle_on_cpu():
 
 def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
     # every tile / LDS / table index of every pass shape stays in bounds (global buffers are exactly n * batch words,
-    # the LDS array exactly LDS_WORDS + 1): 2^0..2^11 with ragged batches, 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
+    # the LDS array exactly LDS_WORDS): 2^0..2^11 with ragged batches (2^11 also through the single-sweep LDS kernel in all its
+    # workgroup shapes), 2^13 / 2^15 (single-sweep, 32-row tiles), 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
     exe = entry.build_emu_sanitized()
-    res = subprocess.run([exe, "11", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6"], capture_output=True, text=True, timeout=900)
+    res = subprocess.run([exe, "11", "13", "15", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "ALL OK" in res.stdout
