@@ -106,7 +106,7 @@ def main():
         assert torch.equal(back, cols), f"4-step inverse log_n={log_n} rank={rank}"
 
     # ---- 3. slab form (no local transposes), same single all-to-all
-    for log_n in (13, 14):
+    for log_n in (13, 14, 16):
         l1 = tdist.first_pass_log(log_n)
         if (1 << (log_n - l1)) < 32 * world:
             continue

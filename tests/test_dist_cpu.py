@@ -15,7 +15,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gloo_sharding_and_fourstep(world):
     import __graft_entry__ as entry
     entry.build_hip()

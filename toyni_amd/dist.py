@@ -174,6 +174,8 @@ def fourstep_forward(cols: torch.Tensor, log_n: int, ops, rank: int = 0, world: 
     c, r = n2 // world, n1 // world
     assert cols.shape == (n1, c)
     t = cols.t().contiguous()                      # [c, n1]: row = column j2 of the matrix
+    if t.data_ptr() == cols.data_ptr():            # a one-column block transposes to a view: do not overwrite the caller's input
+        t = t.clone()
     ops.ntt_rows(t, False)                         # n1-point transforms over j1
     ops.twiddle(t, rank * c, False)                # * w_n^(j2 k1)
     send = t.view(c, world, r).permute(1, 0, 2).contiguous()   # [G, c, r]: block h = k1 in rank h's chunk
