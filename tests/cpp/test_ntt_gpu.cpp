@@ -11,6 +11,8 @@ uint64_t orc_bb_root_of_unity(uint32_t);
 int orc_ntt(uint64_t*, size_t, uint64_t);
 int orc_fri_fold(uint64_t*, const uint64_t*, size_t, const uint64_t*, uint64_t);
 int orc_domain_elements(uint64_t*, size_t, uint64_t);
+uint64_t orc_bb_mul(uint64_t, uint64_t);
+uint64_t orc_bb_add(uint64_t, uint64_t);
 }
 
 using toyni::BabyBear;
@@ -67,11 +69,38 @@ static void test_buffer_and_fold() {
     EXPECT(threw, "odd length must throw");
 }
 
+// src/math/domain.rs:220-242 (coset FFT == Horner at every coset point, shift 7, n = 8, 1 + 2x + 3x^2) and :193-218 (round trips)
+static void test_domain_coset_fft_matches_horner() {
+    if (!ntt::cuda_available()) return;
+    toyni::BabyBearDomain domain = toyni::BabyBearDomain(8).with_gpu(true).get_coset({7});
+    const std::vector<BabyBear> coeffs = {{1}, {2}, {3}};
+    std::vector<BabyBear> evals = domain.fft(coeffs);
+    std::vector<uint64_t> points(8);
+    orc_domain_elements(points.data(), 8, 7);
+    for (size_t i = 0; i < 8; ++i) {
+        const uint64_t x = points[i];
+        const uint64_t want = orc_bb_add(1, orc_bb_add(orc_bb_mul(2, x), orc_bb_mul(3, orc_bb_mul(x, x))));
+        EXPECT(evals[i].value == want, "coset FFT mismatch at %zu", i);
+    }
+    std::vector<BabyBear> back = domain.ifft(evals);
+    for (size_t i = 0; i < 8; ++i) EXPECT(back[i].value == (i < 3 ? coeffs[i].value : 0), "coset round trip at %zu", i);
+    // a larger extension: 2^10 coefficients on a 2^15-point coset, back through ifft
+    toyni::BabyBearDomain lde = toyni::BabyBearDomain(1 << 15).with_gpu(true).get_coset({7});
+    std::vector<BabyBear> poly(1 << 10);
+    for (size_t i = 0; i < poly.size(); ++i) poly[i] = {orc_bb_new(i * 2654435761ull + 17)};
+    std::vector<BabyBear> rt = lde.ifft(lde.fft(poly));
+    for (size_t i = 0; i < rt.size(); ++i) EXPECT(rt[i].value == (i < poly.size() ? poly[i].value : 0), "LDE round trip at %zu", i);
+    bool threw = false;
+    try { toyni::BabyBearDomain(8).fft(coeffs); } catch (const std::logic_error&) { threw = true; }
+    EXPECT(threw, "the mirror has no CPU path");
+}
+
 int main() {
     test_cuda_available();
     test_cuda_ntt_vs_cpu();
     test_cuda_intt_roundtrip();
     test_buffer_and_fold();
+    test_domain_coset_fft_matches_horner();
     std::printf("%s\n", fails ? "CPP FAILED" : "CPP OK");
     return fails ? 1 : 0;
 }

@@ -100,6 +100,50 @@ using CudaBuffer = GpuBuffer;
 
 }  // namespace ntt
 
+// The caller of the hot path, BabyBearDomain (src/math/domain.rs:10-175), restricted to what reaches the GPU: fft / ifft with
+// `use_gpu` set.  Zero padding, coset scaling and the transform are one ABI call each (toyni_lde_host / toyni_coset_ntt_host);
+// the reference pads and scales in serial host loops first (:108-111, :154-174).  Without `with_gpu(true)` this mirror throws:
+// the CPU transform is the reference's own src/ntt.rs.
+class BabyBearDomain {
+  public:
+    explicit BabyBearDomain(size_t size) : size_(size) {
+        if (size == 0 || (size & (size - 1))) throw std::logic_error("Domain size must be power of 2");   // src/math/domain.rs:21
+    }
+    BabyBearDomain get_coset(BabyBear shift) const { BabyBearDomain d(size_); d.shift_ = shift.value % 2013265921ull; d.use_gpu_ = use_gpu_; return d; }  // :34-42
+    BabyBearDomain& with_gpu(bool use_gpu) { use_gpu_ = use_gpu; return *this; }                         // :45-48
+    size_t size() const { return size_; }
+
+    std::vector<BabyBear> fft(const std::vector<BabyBear>& coeffs) const {                               // :107-123
+        toyni_ntt_ctx* ctx = context();
+        std::vector<BabyBear> out(size_);
+        const size_t take = coeffs.size() < size_ ? coeffs.size() : size_;                               // `resize` truncates, :109
+        int st = toyni_lde_host(ctx, reinterpret_cast<const uint64_t*>(coeffs.data()), take, reinterpret_cast<uint64_t*>(out.data()), shift_);
+        if (st != 0) throw std::runtime_error(std::string("GPU NTT failed: ") + toyni_error_string(st));  // `expect`, :116
+        return out;
+    }
+    std::vector<BabyBear> ifft(const std::vector<BabyBear>& evals) const {                               // :85-102
+        if (evals.size() != size_) throw std::logic_error("Evaluation count must match domain size");    // :86
+        toyni_ntt_ctx* ctx = context();
+        std::vector<BabyBear> values = evals;
+        int st = toyni_coset_ntt_host(ctx, reinterpret_cast<uint64_t*>(values.data()), 1, shift_, 1);
+        if (st != 0) throw std::runtime_error(std::string("GPU INTT failed: ") + toyni_error_string(st));
+        return values;
+    }
+
+  private:
+    toyni_ntt_ctx* context() const {
+        if (!use_gpu_) throw std::logic_error("this mirror ships the GPU path only (with_gpu(true)); the CPU transform is src/ntt.rs");
+        if (!ntt::gpu_available()) throw std::runtime_error("GPU not available");
+        std::string err;
+        toyni_ntt_ctx* ctx = ntt::get_or_create_ctx(size_, &err);
+        if (!ctx) throw std::runtime_error(err);
+        return ctx;
+    }
+    size_t size_;
+    uint64_t shift_ = 1;
+    bool use_gpu_ = false;
+};
+
 // src/math/fri.rs:27-48
 inline std::vector<BabyBear> fri_fold(const std::vector<BabyBear>& evals, const std::vector<BabyBear>& xs, BabyBear beta) {
     if (evals.size() % 2) throw std::logic_error("Evaluations length must be even");
