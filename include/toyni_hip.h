@@ -109,6 +109,13 @@ int toyni_lde_host(toyni_ntt_ctx* ctx, const uint64_t* h_coeffs, size_t ncoeffs,
 int toyni_ntt_ext_host(toyni_ntt_ctx* ctx, uint64_t* h_data, uint64_t shift, int inverse);
 int toyni_ntt_ext_device(toyni_ntt_ctx* ctx, uint32_t* d_data, uint32_t shift, int inverse, void* stream);
 
+/* fft_ext of a coefficient vector shorter than the domain (src/math/domain.rs:134-151 pads every coordinate column): the four
+ * coordinate columns as one batch-of-4 low-degree extension, padding implied.  Ext elements are 4 words each (AoS).
+ * host: ncoeffs <= n Ext coefficients (4 * ncoeffs u64) in, n Ext evaluations (4 * n u64) out, only the coefficients uploaded;
+ * device: (n >> log_blowup) Ext coefficients (packed u32 AoS) in, n out, out of place. */
+int toyni_lde_ext_host(toyni_ntt_ctx* ctx, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift);
+int toyni_lde_ext_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_out, unsigned log_blowup, uint32_t shift, void* stream);
+
 /* Multi-GPU 4-step transform of one size-n vector (n = n1 * n2 over G ranks, one all-to-all): the twiddle between
  * the two local stages, d_data[r][k] *= w_n^(+-(row0 + r) * k) for r < rows, k < row_len (ctx of size n;
  * (row0 + rows) * row_len <= n).  The local stages are toyni_ntt_device batches; the exchange is the caller's

@@ -728,6 +728,31 @@ def test_lde_host_is_domain_fft(ta, log_n, ncoeffs):
         assert (ta.ntt.get_or_create_ctx(n).lde_host(big, shift=7) == want).all()
 
 
+@pytest.mark.parametrize("log_n,ncoeffs", [(0, 1), (4, 5), (10, 0), (10, 1000), (12, 64), (16, 3000), (20, 1 << 15), (21, 1 << 21)])
+def test_lde_ext_is_four_base_extensions(ta, log_n, ncoeffs):
+    # fft_ext (src/math/domain.rs:134-151) = the four coordinate columns through fft; host and device forms
+    n = 1 << log_n
+    c4 = oracle.splitmix(4 * ncoeffs, 6500 + log_n).reshape(ncoeffs, 4) if ncoeffs else np.zeros((0, 4), dtype=np.uint64)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    got = ctx.lde_ext_host(c4, shift=7)
+    assert got.shape == (n, 4)
+    for k in range(4):
+        want = oracle.domain_fft(np.ascontiguousarray(c4[:, k]), n, 7) if ncoeffs else np.zeros(n, dtype=np.uint64)
+        assert (got[:, k] == want).all(), f"coordinate {k}"
+    if ncoeffs and ncoeffs & (ncoeffs - 1) == 0:             # device form: power-of-two coefficient counts
+        a, o = DevBuf(ta, 16 * ncoeffs), DevBuf(ta, 16 * n)
+        a.upload(c4.astype(np.uint32))
+        check = ta._lib.check
+        check(ta._lib.lib.toyni_lde_ext_device(ctx.handle, a.ptr, o.ptr, log_n - (ncoeffs.bit_length() - 1), 7, None), "lde ext")
+        ctx.synchronize()
+        dev = o.download(np.uint32, 4 * n).reshape(n, 4)
+        a.free()
+        o.free()
+        assert (dev.astype(np.uint64) == got).all()
+    # and the domain mirror (what a caller of BabyBearDomain::fft_ext sees)
+    assert (ta.BabyBearDomain(n).with_gpu(True).get_coset(7).fft_ext(c4) == got).all()
+
+
 def test_lde_rejects_bad_arguments(ta):
     ctx = ta.ntt.get_or_create_ctx(1 << 12)
     buf = DevBuf(ta, 4 << 12)

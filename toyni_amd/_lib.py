@@ -76,6 +76,8 @@ SIGNATURES = {
     "toyni_lde_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_domain_elements_device": (c_int, [c_void_p, c_void_p, c_size, c_u32, c_void_p]),
     "toyni_lde_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_u64]),
+    "toyni_lde_ext_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_u64]),
+    "toyni_lde_ext_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_ntt_ext_host": (c_int, [c_void_p, c_void_p, c_u64, c_int]),
     "toyni_ntt_ext_device": (c_int, [c_void_p, c_void_p, c_u32, c_int, c_void_p]),
     "toyni_fourstep_twiddle_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),

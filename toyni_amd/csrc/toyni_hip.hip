@@ -156,11 +156,12 @@ __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__
 // Ext (4 coordinates per element, AoS) <-> four base-field columns (SoA): the de-interleave / recombine of
 // BabyBearDomain::transform_ext (src/math/domain.rs:140-151), on the device.  IN = uint64_t (host layout, reduced) or uint32_t.
 template <class IN>
-__global__ void __launch_bounds__(256) ext_split_kernel(const IN* __restrict__ aos, uint32_t* __restrict__ soa, size_t n) {
+__global__ void __launch_bounds__(256) ext_split_kernel(const IN* __restrict__ aos, uint32_t* __restrict__ soa, size_t n, size_t col_stride) {
+    // n elements in; coordinate k goes to soa[k * col_stride ..] (col_stride >= n: a compact LDE input is padded to a power of two)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) soa[(size_t)k * n + i] = (uint32_t)(aos[4 * i + k] % BB_P);
+        for (int k = 0; k < 4; ++k) soa[(size_t)k * col_stride + i] = (uint32_t)(aos[4 * i + k] % BB_P);
     }
 }
 template <class OUT>
@@ -908,7 +909,7 @@ int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int i
     if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, total, sizeof(uint64_t)))) return rc;
     if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_stage64, c->d_data32, n);
+    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_stage64, c->d_data32, n, n);
     if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, (uint32_t)shift))) return rc;
     hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
     HIPCHK(hipGetLastError());
@@ -927,7 +928,7 @@ int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, c->d_data32, n);
+    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, c->d_data32, n, n);
     if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, shift))) return rc;
     hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, d_data, n);
     return (int)hipGetLastError();
@@ -936,6 +937,56 @@ int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int
 int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint64_t shift, int inverse) {
     if (shift >= BB_P) shift %= BB_P;
     return host_transform(c, h_data, batch, (uint32_t)shift, inverse);
+}
+
+// fft_ext of a short coefficient vector (src/math/domain.rs:134-151 pads each coordinate column to the domain size): the
+// four coordinate columns as one batch-of-4 low-degree extension, padding implied
+static int enqueue_lde_ext(toyni_ntt_ctx* c, size_t compact, uint32_t shift, hipStream_t s) {
+    // in: c->d_lde32 = [4][compact] coordinate columns; out: c->d_data32 = [4][n]
+    const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
+    return enqueue_lde(c, c->d_lde32, c->d_data32, 4, log_blowup, shift, s);
+}
+
+int toyni_lde_ext_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, unsigned log_blowup, uint32_t shift, void* stream) {
+    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n || d_coeffs == d_out) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = c->n, n_in = n >> log_blowup;
+    int rc;
+    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, 4 * n_in, sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n_in)), dim3(256), 0, s, d_coeffs, c->d_lde32, n_in, n_in);
+    if ((rc = enqueue_lde_ext(c, n_in, shift, s))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, d_out, n);
+    return (int)hipGetLastError();
+}
+
+int toyni_lde_ext_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift) {
+    if (!c || !h_out || (!h_coeffs && ncoeffs)) return TOYNI_E_NULL;
+    shift %= BB_P;
+    if (shift == 0 || ncoeffs > (size_t)c->n) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    const size_t n = c->n;
+    if (ncoeffs == 0) { std::memset(h_out, 0, 4 * n * sizeof(uint64_t)); return TOYNI_OK; }
+    size_t compact = 1;
+    while (compact < ncoeffs) compact <<= 1;
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, 4 * n, sizeof(uint64_t)))) return rc;
+    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, 4 * compact, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_stage64, h_coeffs, 4 * ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(c->d_lde32, 0, 4 * compact * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(ncoeffs)), dim3(256), 0, s, c->d_stage64, c->d_lde32, ncoeffs, compact);
+    if ((rc = enqueue_lde_ext(c, compact, (uint32_t)shift, s))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->d_stage64, 4 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return TOYNI_OK;
 }
 
 // ---- multi-GPU 4-step helper: the twiddle between the two local transform stages ----

@@ -58,9 +58,12 @@ class BabyBearDomain:
     def _transform_ext(self, vals4, inverse: bool) -> np.ndarray:
         self._require_gpu()
         v = np.asarray(vals4, dtype=np.uint64).reshape(-1, 4)
-        assert v.shape[0] <= self.size if not inverse else v.shape[0] == self.size
-        vals = np.zeros((self.size, 4), dtype=np.uint64)  # zero-pad like fft (src/math/domain.rs:109)
-        vals[: v.shape[0]] = v
-        # the de-interleave / four transforms / recombine of src/math/domain.rs:140-151 happen on the device in one call
-        _ntt.get_or_create_ctx(self.size).run_host_ext(vals.reshape(-1), inverse=inverse, shift=self.shift)
+        ctx = _ntt.get_or_create_ctx(self.size)
+        if not inverse:
+            assert v.shape[0] <= self.size
+            # zero padding of :136-137 implied on the device; de-interleave / four transforms / recombine (:140-151) in one call
+            return ctx.lde_ext_host(v, shift=self.shift)
+        assert v.shape[0] == self.size
+        vals = v.copy()
+        ctx.run_host_ext(vals.reshape(-1), inverse=True, shift=self.shift)
         return vals

@@ -128,6 +128,13 @@ class NttContext:
         check(lib.toyni_lde_host(self.handle, c.ctypes.data if c.size else None, c.size, out.ctypes.data, shift), "GPU LDE failed")
         return out
 
+    def lde_ext_host(self, coeffs4: np.ndarray, shift: int = 1) -> np.ndarray:
+        """fft_ext of ncoeffs <= n Ext coefficients ([ncoeffs, 4] u64): [n, 4] evaluations on shift * <w_n>, padding implied."""
+        c = np.ascontiguousarray(coeffs4, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty((self.n, 4), dtype=np.uint64)
+        check(lib.toyni_lde_ext_host(self.handle, c.ctypes.data if c.size else None, c.shape[0], out.ctypes.data, shift), "GPU Ext LDE failed")
+        return out
+
     def run_host_ext(self, values4: np.ndarray, inverse: bool, shift: int = 1) -> None:
         """n Ext elements ([n, 4] u64, AoS) in place: the four coordinate transforms as one batch, one PCIe round trip."""
         v = _as_u64(values4)
