@@ -655,6 +655,8 @@ def test_both_executors_of_the_single_sweep_sizes(ta):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pp = os.pathsep.join([root, os.path.join(root, "tests")])
     modes = [("two-pass", {"TOYNI_NO_LDS_KERNEL": "1", "TOYNI_TEST_LAUNCHES": "2"}),
+             # the non-temporal kernel variants (normally chosen for footprints >= 512 MiB) forced on small data
+             ("two-pass, non-temporal", {"TOYNI_NO_LDS_KERNEL": "1", "TOYNI_NT_MIN_BYTES": "0", "TOYNI_TEST_LAUNCHES": "2"}),
              ("sweep, 4 workgroups per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_TEST_LAUNCHES": "1"}),
              ("sweep, 1 workgroup per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_LDS_ROWS": "5", "TOYNI_TEST_LAUNCHES": "1"})]
     for mode, extra in modes:

@@ -16,6 +16,15 @@ __global__ void copy4(const uint32_t* __restrict__ in, uint32_t* __restrict__ ou
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
 }
+// the same with non-temporal hints (streaming data: read once, written once)
+template <int LD_NT, int ST_NT>
+__global__ void copy4_nt(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = LD_NT ? __builtin_nontemporal_load(in + i) : in[i];
+        if (ST_NT) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+    }
+}
 // column tile: tile = C columns x M rows of a [M][S] matrix (row stride ld words); 32 elements per thread, like the pass.
 // mode 0: read strided, write same place (in-place layout, other buffer); mode 1: read strided only (sum -> rare store); mode 2: write strided only
 template <int C, int MODE>
@@ -64,6 +73,16 @@ int main() {
     printf("copy16 contiguous           : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
     ms = timeit([&] { hipLaunchKernelGGL(copy4, dim3(2048), dim3(256), 0, 0, in, out, n); }, 10);
     printf("copy4 contiguous            : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((copy4_nt<1, 0>), dim3(2048), dim3(256), 0, 0, in, out, n); }, 10);
+    printf("copy4 nt-load               : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((copy4_nt<0, 1>), dim3(2048), dim3(256), 0, 0, in, out, n); }, 10);
+    printf("copy4 nt-store              : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((copy4_nt<1, 1>), dim3(2048), dim3(256), 0, 0, in, out, n); }, 10);
+    printf("copy4 nt-load + nt-store    : %.3f ms  %.2f TB/s (r+w)\n", ms, 2.0 * n * 4 / ms / 1e9);
+    for (int g : {1024, 4096, 8192}) {
+        ms = timeit([&] { hipLaunchKernelGGL(copy4, dim3(g), dim3(256), 0, 0, in, out, n); }, 10);
+        printf("copy4 contiguous grid %5d : %.3f ms  %.2f TB/s (r+w)\n", g, ms, 2.0 * n * 4 / ms / 1e9);
+    }
     const uint32_t M = 1024, log_s = 10;
     for (int grid : {256, 512}) {
         const uint32_t nt32 = (uint32_t)(n / (M * 32)), nt16 = (uint32_t)(n / (M * 16));

@@ -138,15 +138,17 @@ inline bool build_plan(int log_n, NttPlan& plan) {
 // But a tile is 32 K elements, so a SINGLE 2^20 transform is only 32 tiles; when the launch has too few tiles to
 // cover the chip the narrower variants (16 / 8 wide) are used -- the data is cache-resident at that size anyway.
 // `log_tiles32` = log2 of the number of 32-wide tiles the launch would have.
+// nt: the non-temporal variant of the same shape (streaming launches, see ld32 / st32).
 template <class F>
-inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f) {
+inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
+#define TOYNI_PASS_GO(K, A, B, LC_) do { if (nt) f(Pass<K, A, B, LC_, true>{}); else f(Pass<K, A, B, LC_, false>{}); } while (0)
 #define TOYNI_PASS_CASE(K, A, B, LC_) \
-    if (kind == K && log_m == (A) + (B)) { f(Pass<K, A, B, LC_>{}); return true; }
+    if (kind == K && log_m == (A) + (B)) { TOYNI_PASS_GO(K, A, B, LC_); return true; }
 #define TOYNI_PASS_CASE_W(K, A, B)                                                    \
     if (kind == K && log_m == (A) + (B)) {                                             \
-        if (log_tiles32 >= 9) f(Pass<K, A, B, 5>{});                                   \
-        else if (log_tiles32 >= 7) f(Pass<K, A, B, 4>{});                              \
-        else f(Pass<K, A, B, 3>{});                                                    \
+        if (log_tiles32 >= 9) TOYNI_PASS_GO(K, A, B, 5);                               \
+        else if (log_tiles32 >= 7) TOYNI_PASS_GO(K, A, B, 4);                          \
+        else TOYNI_PASS_GO(K, A, B, 3);                                                \
         return true;                                                                   \
     }
     // strided column passes (first / middle passes of a 2- or 3-pass transform)
@@ -175,6 +177,7 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f) {
     TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
 #undef TOYNI_PASS_CASE
 #undef TOYNI_PASS_CASE_W
+#undef TOYNI_PASS_GO
     return false;
 }
 
@@ -226,7 +229,7 @@ struct CosetTables {
 template <class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
                           uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables(),
-                          int lde_log = 0) {
+                          int lde_log = 0, bool nt = false) {
     if (plan.log_n == 0 || batch == 0) return true;  // n = 1: identity
     if (lde_log && (inverse || plan.npasses < 2 || lde_log > plan.pass[0].log_m)) return false;
     const uint64_t total_log = (uint64_t)plan.log_n;
@@ -276,7 +279,7 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         };
         bool ok;
         if (p == 0 && lde_log) ok = dispatch_pass_lz(pp.log_m, log_tiles32, lde_log < 5 ? lde_log : 5, body);
-        else ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); });
+        else ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); }, nt);
         if (!ok) return false;
     }
     return true;

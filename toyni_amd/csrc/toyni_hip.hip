@@ -35,7 +35,7 @@ using namespace toyni;
 //     behind them -- all of it BEFORE the current tile's stores, in flight across the barrier and the whole of step 2.
 // The barriers are raw s_barrier with an explicit LDS-only wait: __syncthreads() would also drain vmcnt.
 template <class P> struct PassKindOf;
-template <int K, int A, int B, int C> struct PassKindOf<Pass<K, A, B, C>> { static constexpr int value = K; };
+template <int K, int A, int B, int C, bool N> struct PassKindOf<Pass<K, A, B, C, N>> { static constexpr int value = K; };
 template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
 
 // LZ > 0: first pass of a low-degree extension -- the input holds only the leading n >> LZ words of every transform
@@ -464,15 +464,6 @@ int grid_for(size_t items, int block = 256) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// prefetch variants (TOYNI_PREFETCH = 0 | 32: none / the whole next tile; tuning knob, 32 is the measured default)
-int prefetch_depth() {
-    static const int depth = [] {
-        const char* env = std::getenv("TOYNI_PREFETCH");
-        return env ? std::atoi(env) : 32;
-    }();
-    return depth;
-}
-
 // When the single-sweep kernel runs instead of the two-pass plan: sizes 2^11 .. 2^TOYNI_LDS_MAX_LOG (default 13; 10 = never,
 // 15 = every size it exists for) and launches of at least TOYNI_LDS_MIN_ELEMS elements (default 2^25).  Measured
 // (profiles/r01_sweep_lds.txt): it halves the HBM traffic and is 5-19 % faster on large batches of 2^11 .. 2^13, but the sweep is
@@ -497,6 +488,16 @@ bool lds_kernel_enabled(const NttPlan& plan, uint64_t batch) {
     return plan.lds_la != 0 && plan.log_n <= lds_max_log() && (batch << plan.log_n) >= lds_min_elems();
 }
 
+// footprint (bytes of one call's data) from which the pass kernels use non-temporal loads / stores; TOYNI_NT_MIN_BYTES,
+// default 512 MiB = twice the Infinity Cache (0 = always, a huge value = never)
+uint64_t nt_min_bytes() {
+    static const uint64_t v = [] {
+        const char* env = std::getenv("TOYNI_NT_MIN_BYTES");
+        return env ? (uint64_t)std::strtoull(env, nullptr, 0) : (uint64_t)512 << 20;
+    }();
+    return v;
+}
+
 // rows per workgroup of the single-sweep kernel, as a power of two (TOYNI_LDS_ROWS = 3 | 4 | 5; tuning knob; 8 rows =
 // four 256-thread workgroups per CU measured best)
 int lds_log_rows() {
@@ -504,14 +505,10 @@ int lds_log_rows() {
     return v;
 }
 
+// PF = 32: the whole next tile is prefetched (0 / 16 measured within 1 % and dropped; the template parameter remains for experiments)
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
-    if constexpr (LZ > 0) {  // low-degree-extension first pass: one variant (the prefetch knob applies to the whole-input kernels)
-        hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
-    } else {
-        if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
-        else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
-    }
+    hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
 }
 
 // Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
@@ -589,6 +586,8 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (rc) return rc;
     }
     const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
+    // streaming launches (footprint well beyond the 256 MiB Infinity Cache) take the non-temporal kernels
+    const bool nt = lde_log == 0 && (uint64_t)batch * n * sizeof(uint32_t) >= nt_min_bytes();
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
@@ -611,7 +610,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                         (void)hipEventRecord(rec.e1, s);
                                         c->timing_recs.push_back(rec);
                                     }
-                                }, cs, lde_log);
+                                }, cs, lde_log, nt);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
     }
