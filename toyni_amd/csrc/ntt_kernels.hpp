@@ -84,12 +84,11 @@ template <bool NT = false>
 TOYNI_HD uint32_t ld32(const uint32_t* base, uint32_t byte_off) {
 #if TOYNI_ABLATE & 1
     return (uint32_t)(reinterpret_cast<uintptr_t>(base) >> 2) + byte_off;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off));
+    else return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
 #else
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (NT) return __builtin_nontemporal_load(p);
-#endif
-    return *p;
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + byte_off);
 #endif
 }
 template <bool NT = false>
@@ -97,13 +96,11 @@ TOYNI_HD void st32(uint32_t* base, uint32_t byte_off, uint32_t v) {
 #if TOYNI_ABLATE & 2
     if (v == 0xFFFFFFFFu)
 #endif
-    {
-        uint32_t* p = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (NT) { __builtin_nontemporal_store(v, p); return; }
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off));
+    else
 #endif
-        *p = v;
-    }
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
 constexpr uint32_t cx_bitrev(uint32_t x, int bits) {
@@ -591,16 +588,13 @@ struct LdsPass {
             }
         }
     }
-    // the thread's own constants: w_n^j' and (forward coset transform) s^j' for each of its columns
-    struct Seeds { uint32_t g[NCOL], cs_a[NCOL]; };
+    // the thread's own constants, held across tiles: w_n^j' for each of its columns.  (The forward coset factor s^j' is
+    // looked up per tile instead -- four more live registers push the 8-row shapes over the 128-VGPR budget.)
+    struct Seeds { uint32_t g[NCOL]; };
     static TOYNI_HD Seeds seedsA(const LdsArgs& g, uint32_t tid) {
         Seeds s;
 #pragma unroll
-        for (uint32_t c = 0; c < NCOL; ++c) {
-            const uint32_t j = tid + c * T;
-            s.g[c] = g.gtab[j];
-            s.cs_a[c] = g.cs_mode == 1u ? mont_mul(g.cs_hi[j >> g.cs_lowbits], g.cs_lo[j & ((1u << g.cs_lowbits) - 1u)]) : 0u;
-        }
+        for (uint32_t c = 0; c < NCOL; ++c) s.g[c] = g.gtab[tid + c * T];
         return s;
     }
     static TOYNI_HD void phaseA(const LdsArgs& g, uint32_t tid, uint32_t (&x)[E], const Seeds& sd, const Uniform& uni, uint32_t* lds) {
@@ -610,7 +604,9 @@ struct LdsPass {
             for (uint32_t r = 0; r < R; ++r) {
                 uint32_t (&xr)[MA] = *reinterpret_cast<uint32_t (*)[MA]>(&x[(c * R + r) * MA]);
                 if (g.cs_mode == 1u) {   // x[j] *= s^j, j = j_a * 1024 + j'
-                    uint32_t tw = sd.cs_a[c];
+                    uint32_t j = tid + c * T;
+                    TOYNI_PIN(j);        // opaque: keeps the lookup inside the tile loop (hoisted, it would cost NCOL live registers)
+                    uint32_t tw = mont_mul(g.cs_hi[j >> g.cs_lowbits], g.cs_lo[j & ((1u << g.cs_lowbits) - 1u)]);
 #pragma unroll
                     for (uint32_t ja = 0; ja < MA; ++ja) {
                         xr[ja] = mont_mul(xr[ja], tw);

@@ -505,10 +505,25 @@ int lds_log_rows() {
     return v;
 }
 
-// PF = 32: the whole next tile is prefetched (0 / 16 measured within 1 % and dropped; the template parameter remains for experiments)
+// prefetch variants (TOYNI_PREFETCH = 0 | 32: none / the whole next tile; tuning knob, 32 is the measured default).  Both are
+// kept instantiated for the plain kernels: with a single caller per pass shape the inliner makes different choices and the
+// 1024-point row pass ends up spilling (measured: 99 VGPRs / no scratch with both variants, 128 / 132 B scratch with one).
+int prefetch_depth() {
+    static const int depth = [] {
+        const char* env = std::getenv("TOYNI_PREFETCH");
+        return env ? std::atoi(env) : 32;
+    }();
+    return depth;
+}
+
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
-    hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    if constexpr (LZ > 0) {  // LDE first pass: one kernel each
+        hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    } else {
+        if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    }
 }
 
 // Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
