@@ -283,7 +283,7 @@ def main():
         cfile = os.path.join(ROOT, "profiles", "r01_counters.json")
         if os.path.exists(cfile) and traffic is not None:
             cj = json.load(open(cfile))
-            per_launch = {("Pass<0" if "Pass<0" in k else "Pass<1"): v.get("SQ_INSTS_VALU") for k, v in cj.items() if "ntt_pass_kernel" in k and "5, 5, 5>" in k}
+            per_launch = {("Pass<0" if "Pass<0" in k else "Pass<1"): v.get("SQ_INSTS_VALU") for k, v in cj.items() if "ntt_pass_kernel" in k and "5, 5, 5" in k}
             if all(per_launch.get(x) for x in ("Pass<0", "Pass<1")):
                 lane_ops_per_elem = (per_launch["Pass<0"] + per_launch["Pass<1"]) * 64.0 / (n * batch)
                 t_fwd = sum(fwd_ms) * 1e-3
