@@ -217,7 +217,11 @@ __global__ void __launch_bounds__(256) domain_elements_kernel(uint32_t* __restri
     }
 }
 
-// FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the non-temporal builtins accept for 16-byte accesses
+
+// FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows.
+// NT: non-temporal accesses for layers far larger than the Infinity Cache (read once, written once).
+template <bool NT>
 __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
     const uint64_t half = f.half;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -226,13 +230,27 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
         const uint4* eb = reinterpret_cast<const uint4*>(f.evals + half);
         uint4* o = reinterpret_cast<uint4*>(f.out);
         for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < half / 4; q += stride) {
-            const uint4 a = ea[q], b = eb[q];
+            uint4 a, b;
+            if constexpr (NT) {
+                const u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ea + q));
+                const u32x4 vb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(eb + q));
+                a = make_uint4(va.x, va.y, va.z, va.w);
+                b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+            } else {
+                a = ea[q];
+                b = eb[q];
+            }
             uint4 r;
             r.x = fold_one(f, 4 * q + 0, a.x, b.x);
             r.y = fold_one(f, 4 * q + 1, a.y, b.y);
             r.z = fold_one(f, 4 * q + 2, a.z, b.z);
             r.w = fold_one(f, 4 * q + 3, a.w, b.w);
-            o[q] = r;
+            if constexpr (NT) {
+                u32x4 vr = {r.x, r.y, r.z, r.w};
+                __builtin_nontemporal_store(vr, reinterpret_cast<u32x4*>(o + q));
+            } else {
+                o[q] = r;
+            }
         }
     } else {
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
@@ -1101,7 +1119,8 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
     const size_t work = (f.half & 3) ? f.half : f.half / 4;
-    hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(work)), dim3(256), 0, s, f);
+    if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) hipLaunchKernelGGL(fri_fold_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL(fri_fold_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, f);
     return (int)hipGetLastError();
 }
 
