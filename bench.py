@@ -40,48 +40,61 @@ def parse():
     ap.add_argument("--chunks", type=int, default=1, help="slab workload: issue the exchange in this many asynchronous pieces")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the pass launches of the timed region with HIP events (A/B check of their cost)")
+    ap.add_argument("--probe-ranks", action="store_true",
+                    help="launch check without a GPU: the ranks rendezvous over gloo, count themselves and exit (tests/test_bench_launch.py)")
     ap.add_argument("--workload", choices=["batch", "fourstep", "slab"], default="batch",
                     help="batch: the default sharded batch (weak scaling); fourstep: ONE transform of n = 2^log-n split over "
                          "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit)")
     return ap.parse_args()
 
 
+def _oracle_bench_binary():
+    """oracle/build/bench_oracle, rebuilt HERE with gcc -O3 -march=native: the binary is native to the host that
+    times it (the in-tree copy may come from another machine's CPU)."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    exe = os.path.join(odir, "build", "bench_oracle")
+    if os.path.exists(exe):
+        os.remove(exe)
+    subprocess.check_call(["make", "-C", odir, "bench"], stdout=subprocess.DEVNULL)
+    return exe
+
+
 def cpu_baseline(log_n, seconds):
-    """The oracle (C restatement of src/ntt.rs:24-66, u128 % multiply) on one host core: forward + inverse at n."""
-    import numpy as np
-    import oracle
-    n = 1 << log_n
-    x = oracle.splitmix(n, 0xB45E)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        y = oracle.ntt(x)
-        x2 = oracle.intt(y)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or reps >= 200:
-            break
-    assert (x2 == x).all()
-    # all-cores variant (SURVEY 8(d)): one independent transform stream per worker PROCESS (never fork a process that has
-    # initialised the GPU: plain child interpreters), a few seconds each
+    """The oracle (C restatement of src/ntt.rs:24-66 and src/math/fri.rs:27-48, u128 % multiply) timed in a C loop on this
+    box's host cores: forward + inverse NTT at n on one thread (the reference is single-threaded), the same on all cores
+    (one independent stream per process), and the FRI fold of a 2^20 layer on one thread."""
     import shutil
     import subprocess
+    exe = _oracle_bench_binary()
+    n = 1 << log_n
+
+    def run(kind, lg, secs):
+        o = subprocess.run([exe, kind, str(lg), str(secs)], capture_output=True, text=True, check=True).stdout.split()
+        return int(o[2]), float(o[3])
+
+    reps, el = run("ntt", log_n, seconds)
     workers = min(os.cpu_count() or 1, 64)
-    code = ("import sys,time;sys.path.insert(0,%r);import oracle;n=1<<%d;x=oracle.splitmix(n,7);t0=time.perf_counter();r=0\n"
-            "while time.perf_counter()-t0<%f:\n y=oracle.ntt(x);x=oracle.intt(y);r+=1\n"
-            "print(r,time.perf_counter()-t0)") % (ROOT, log_n, max(2.0, seconds / 3))
-    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(workers)]
+    procs = [subprocess.Popen([exe, "ntt", str(log_n), str(max(2.0, seconds / 3))], stdout=subprocess.PIPE, text=True) for _ in range(workers)]
     tot = 0.0
     for p in procs:
         o = p.communicate()[0].split()
-        if len(o) == 2:
-            tot += 2 * int(o[0]) * n / float(o[1])
+        if len(o) >= 4:
+            tot += 2 * int(o[2]) * n / float(o[3])
+    fold_log = 20
+    freps, fel = run("fold", fold_log, max(2.0, seconds / 3))
+    fold_bytes = 6.0 * (1 << fold_log)          # algorithmic: 4 B read per input element + 2 B written (SURVEY 8(d))
     return {
         "value": 2 * reps * n / el, "unit": "elements/s", "cores": 1, "kind": "port",
-        "sample": f"{reps} x (forward + inverse) NTT n=2^{log_n} on 1 thread, {el:.1f} s; oracle/toyni_oracle.c "
-                  f"(reference algorithm src/ntt.rs:24-66; the Rust reference itself cannot be built here)",
+        "sample": f"{reps} x (forward + inverse) NTT n=2^{log_n} on 1 thread, {el:.1f} s; oracle/toyni_oracle.c timed by "
+                  f"oracle/bench_oracle.c (gcc -O3 -march=native, C loop; reference algorithm src/ntt.rs:24-66; the Rust "
+                  f"reference itself cannot be built here)",
         "host_cpus": os.cpu_count(),
         "all_cores": {"value": tot, "unit": "elements/s", "cores": workers, "note": "one independent transform stream per process"},
+        "fold": {"value": freps * fold_bytes / fel / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                 "elements_per_s": freps * (1 << fold_log) / fel,
+                 "sample": f"{freps} x fri_fold of a 2^{fold_log} layer (xs = 7 w^i, one Fermat inversion per output as "
+                           f"src/math/fri.rs:27-48), 1 thread, {fel:.1f} s; 6 B per input element"},
         "rust_toolchain_present": shutil.which("cargo") is not None,
     }
 
@@ -128,7 +141,8 @@ def bench_fourstep(args, dev, rank, world, distributed):
     if rank == 0:
         print(json.dumps({
             "metric": "BabyBear NTT throughput, single transform split over GPUs (%s, one all-to-all)" % ("slab form" if slab else "4-step"), "value": 2 * args.steps * (1 << log_n) / wall,
-            "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "unit": "elements/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"forward+inverse {'slab-form' if slab else '4-step'} NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
                        "log_n": log_n, "parallelism": f"column/row split x{world}, RCCL all-to-all"},
@@ -139,8 +153,48 @@ def bench_fourstep(args, dev, rank, world, distributed):
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the driver's SCALE runs): start the N ranks here.
+
+    This process has not imported torch or touched HIP yet, and it never will: the ranks run in a child
+    `python -m torch.distributed.run` (one process per GPU, RCCL), whose output and exit code are passed through.  A child
+    process, not an exec: nothing GPU-related is ever replaced in place."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def probe_ranks(args):
+    """What `--gpus N` starts, checked without a GPU: every rank joins a gloo group and adds 1; rank 0 prints the count."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "ranks_counted": int(t.item()), "requested_gpus": args.gpus}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.probe_ranks:
+        return probe_ranks(args)
     import numpy as np
     import torch
 
@@ -236,7 +290,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "BabyBear NTT throughput (forward+inverse, device-resident)", "value": value, "unit": "elements/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1, "collective_backend": backend if distributed else None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over a batch of {batch} transforms per GPU "

@@ -36,7 +36,9 @@ typedef struct toyni_ntt_ctx toyni_ntt_ctx;
 
 /* ------------------------------------------------------------------------------------------------
  * 1. The reference's ABI, symbol for symbol (cuda/ntt_kernel.cu:211-318; extern block src/ntt.rs:95-110).
- *    The reference's own src/ntt.rs links against these unchanged.  `count` is in u64 ELEMENTS.
+ *    The reference's own extern block binds these nine with TWO edits: the link name
+ *    (`ntt_cuda` -> `toyni_hip`) and `cudaGetDeviceCount` (libcudart, src/ntt.rs:102) -> toyni_device_count.
+ *    `count` is in u64 ELEMENTS.
  * ---------------------------------------------------------------------------------------------- */
 void* ntt_ctx_create(uint32_t n);                       /* cuda/ntt_kernel.cu:213-234; NULL on error */
 void ntt_ctx_destroy(void* ctx);                        /* :236-242; null-safe */

@@ -1,7 +1,9 @@
 // build.rs for Toyni with the MI355X backend (replaces the reference's nvcc-driving build.rs:27-118).
 //
-// UNVERIFIED BY A COMPILER: the build image has no cargo/rustc.  Kept deliberately
-// small.  It compiles toyni_hip.hip for gfx950 ONLY with hipcc, archives it, links amdhip64, and
+// UNVERIFIED BY rustc: the build image has no cargo/rustc.  Kept deliberately small.  What IS
+// verified (tests/test_rust_dropin.py): the exact hipcc and ar commands below, run in a scratch crate layout
+// (hip/ filled as INTEGRATION.md section 1 says), produce a libtoyni_hip.a that links into a host program with
+// exactly the libraries emitted at the bottom (-lamdhip64 -lstdc++).  It compiles toyni_hip.hip for gfx950 ONLY with hipcc, archives it, links amdhip64, and
 // emits `has_hip` -- which, unlike the reference's unused `has_cuda`, src/ntt.rs
 // really gates on, so `--features hip` on a box without ROCm still builds the CPU path.
 use std::{env, path::PathBuf, process::Command};
@@ -20,6 +22,9 @@ fn main() {
     println!("cargo:rerun-if-changed=hip/ntt_kernels.hpp");
     println!("cargo:rerun-if-changed=hip/ntt_plan.hpp");
     println!("cargo:rerun-if-changed=hip/bb_field.hpp");
+    println!("cargo:rerun-if-changed=hip/merkle_kernels.hpp");
+    println!("cargo:rerun-if-changed=hip/prover_kernels.hpp");
+    println!("cargo:rerun-if-changed=hip/toyni_hip.h");
     println!("cargo::rustc-check-cfg=cfg(has_hip)");
     if env::var_os("CARGO_FEATURE_HIP").is_none() {
         return;
@@ -33,7 +38,7 @@ fn main() {
     let lib = out.join("libtoyni_hip.a");
     // gfx950 (MI355X) is the only target: no other --offload-arch, no CUDA path.
     let ok = Command::new(&hipcc)
-        .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "hip/toyni_hip.hip", "-o"])
+        .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", "hip", "-c", "hip/toyni_hip.hip", "-o"])
         .arg(&obj)
         .status()
         .map(|s| s.success())

@@ -1,0 +1,54 @@
+"""bench.py's launch contract: `python bench.py --gpus N` (no launcher around it, exactly how the driver's SCALE runs start it)
+must itself bring up N ranks -- before anything touches the GPU -- and report n_gpus = N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-3000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4])
+def test_bare_invocation_spawns_ranks(gpus):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--probe-ranks"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = _last_json(res.stdout)
+    assert out["n_gpus"] == gpus and out["ranks_counted"] == gpus
+
+
+def test_under_a_launcher_no_second_spawn():
+    # the contract's other form: the driver starts torch.distributed.run itself; bench.py must then NOT spawn again
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--probe-ranks"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    outs = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(outs) == 1 and json.loads(outs[0])["ranks_counted"] == 2
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_rehearsal():
+    """world = 2 through the real bench body on the one GPU of the box (gloo carries the collectives, both ranks share cuda:0):
+    the batch workload and the slab workload (one all-to-all per transform)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TOYNI_BENCH_BACKEND"] = "gloo"
+    for extra in (["--batch", "8"], ["--workload", "slab", "--log-n", "22"]):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--no-extras", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        out = _last_json(res.stdout)
+        assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_no_kernel_spills_and_occupancy_targets_hold():
     src = os.path.join(ROOT, "toyni_amd", "csrc", "toyni_hip.hip")
     with tempfile.TemporaryDirectory() as tmp:
-        res = subprocess.run([entry._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-o", os.path.join(tmp, "t.o"), src,
+        res = subprocess.run([entry._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-c", "-o", os.path.join(tmp, "t.o"), src,
                               "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900, cwd=tmp)
     assert res.returncode == 0, res.stderr[-3000:]
     assert "loop not unrolled" not in res.stderr          # a stage loop that stays rolled indexes registers dynamically -> scratch

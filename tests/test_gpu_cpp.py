@@ -16,7 +16,7 @@ def _build():
     obj = out + "_oracle.o"
     subprocess.check_call(["gcc", "-O2", "-c", "-o", obj, os.path.join(ROOT, "oracle", "toyni_oracle.c")])
     libdir = os.path.join(ROOT, "toyni_amd", "lib")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, os.path.join(ROOT, "tests", "cpp", "test_ntt_gpu.cpp"), obj,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", out, os.path.join(ROOT, "tests", "cpp", "test_ntt_gpu.cpp"), obj,
                            "-L", libdir, "-ltoyni_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return out
 

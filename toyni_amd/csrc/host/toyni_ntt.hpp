@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../../include/toyni_hip.h"
+#include "toyni_hip.h"  // include/toyni_hip.h (-I include)
 
 namespace toyni {
 

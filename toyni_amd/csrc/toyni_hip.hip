@@ -11,7 +11,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/toyni_hip.h"
+#include "toyni_hip.h"  // include/toyni_hip.h: -I include here; next to this file in a crate's hip/ directory
 #include "ntt_plan.hpp"
 #include "merkle_kernels.hpp"
 
