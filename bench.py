@@ -242,7 +242,7 @@ def main():
     for off in range(0, batch * n, piece):
         m = min(piece, batch * n - off)
         data[off:off + m] = torch.randint(0, P, (m,), dtype=torch.int32, device=dev, generator=gen)
-    check_before = data[: n].clone()
+    check_before = data.clone()          # the WHOLE batch: forward + inverse must leave every transform unchanged
     stream = torch.cuda.current_stream().cuda_stream
     ptr = data.data_ptr()
 
@@ -276,8 +276,19 @@ def main():
     if kernel_events:
         region = ctx.read_timing()
         ctx.timing(False)
-    # forward + inverse leaves the batch unchanged: a free end-to-end sanity check of the timed region
-    assert torch.equal(data[: n], check_before), "round trip changed the data"
+    # forward + inverse leaves the batch unchanged: an end-to-end check of the timed region over EVERY transform (a skipped
+    # or duplicated tile anywhere shows up here), plus -- a round trip is the identity for many wrong transforms too -- one
+    # forward transform (the last of the batch) against the oracle, outside the timed region
+    assert torch.equal(data, check_before), "round trip changed the data"
+    del check_before
+    if rank == 0 and args.log_n <= 22:
+        import oracle
+        last = data[(batch - 1) * n:].clone()
+        ctx.run_device(last.data_ptr(), last.data_ptr(), 1, False, stream=stream)
+        torch.cuda.synchronize()
+        want = oracle.ntt(data[(batch - 1) * n:].cpu().numpy().view(np.uint32).astype(np.uint64))
+        assert (last.cpu().numpy().view(np.uint32) == want).all(), "forward transform differs from the oracle"
+        del last
 
     el = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
     if distributed:

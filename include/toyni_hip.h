@@ -11,8 +11,13 @@
  *   device "u32" : packed uint32_t canonical residues (the native device format; 8 B/element of HBM
  *                  traffic per pass instead of 16).
  *
- * Threading: a context serialises its own calls with an internal mutex (the reference's shared d_data
- * race, SURVEY.md F8, cannot happen).  Different contexts may be used concurrently.
+ * Threading and streams: a context serialises the ENQUEUEING of its calls with an internal mutex, and keeps its
+ * intermediate buffers per stream: calls enqueued on one stream are ordered by that stream, calls enqueued on different
+ * streams use different buffers.  So one context may be driven from several host threads and several streams at once
+ * (the reference's single shared d_data -- SURVEY.md F8, cuda/ntt_kernel.cu:205 -- has no counterpart).  Nothing is freed
+ * on an enqueue path: an outgrown buffer is released after the next synchronisation of its stream through this API
+ * (blocking entry points, toyni_stream_synchronize) or by toyni_ntt_ctx_trim / toyni_ntt_ctx_destroy.  At most 8 streams'
+ * buffer sets are kept per context (least recently used first out).
  */
 #ifndef TOYNI_HIP_H
 #define TOYNI_HIP_H
@@ -31,6 +36,8 @@ extern "C" {
 #define TOYNI_E_NO_DEVICE 10004      /* no usable GPU ("CUDA not available", src/ntt.rs:225-227) */
 #define TOYNI_E_ZERO_INVERSE 10005   /* fri_fold: a point x_i = 0 ("Cannot invert zero", src/babybear.rs:112) */
 #define TOYNI_E_RANGE 10006          /* argument out of range (layer larger than the context's domain, ...) */
+#define TOYNI_E_NO_RCCL 10007        /* the RCCL exchange was requested and librccl could not be loaded */
+#define TOYNI_E_RCCL 10008           /* an RCCL call failed */
 
 typedef struct toyni_ntt_ctx toyni_ntt_ctx;
 
@@ -75,13 +82,14 @@ int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);
 int toyni_ntt_host(toyni_ntt_ctx* ctx, uint64_t* h_data, size_t batch, int inverse);
 
 /* The same over several GPUs from ONE host process: the batch is sharded contiguously over `devices` (ordinals; a
- * device may be listed more than once), one host thread and one context per entry, no collective.  Blocking. */
+ * device may be listed more than once), one host thread per entry, no collective.  Contexts are cached per
+ * (device, lane, n) for the life of the process, like get_or_create_ctx (src/ntt.rs:128-141).  Blocking. */
 int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t* h_data, size_t batch, int inverse);
 
 /* Device-resident, packed u32, in place (d_in == d_out) or out of place.  Enqueued on `stream`
  * (a hipStream_t; NULL = HIP's default stream, as everywhere in HIP) and NOT synchronised: this is the
  * entry point the roofline numbers are measured on.  batch transforms are contiguous (stride n).
- * One stream at a time per context (the intermediate buffer is shared). */
+ * Any number of streams per context (intermediates are per stream, see "Threading and streams" above). */
 int toyni_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, int inverse, void* stream);
 
 /* Device-resident on the reference's u64 element layout (what a CudaBuffer holds, src/ntt.rs:153-215). */
@@ -147,6 +155,24 @@ int toyni_ntt_slab_pass_device(toyni_ntt_ctx* ctx, uint32_t* d_slab, size_t cols
 int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
                                    size_t parts, int inverse, void* stream);
 
+/* 2c. The same transform driven from ONE host process over G = ndev devices (G a power of two; Toyni is a single process,
+ * src/ntt.rs:128-141): slab pass -> ONE exchange -> relayout -> row transforms on every device, contexts, streams and
+ * landing buffers cached per (device list, n).  `exchange` selects how the one exchange step moves its G x G blocks:
+ *   TOYNI_EXCHANGE_PEER_COPY  every destination pulls its blocks with hipMemcpyPeerAsync (xGMI), one copy stream per
+ *                             source so that all incoming links are busy at once; the only form that accepts a device
+ *                             listed more than once (lanes on one device: the copy is then device-local)
+ *   TOYNI_EXCHANGE_RCCL       one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd over ncclCommInitAll
+ *                             communicators; librccl is loaded on first use (dlopen), TOYNI_E_NO_RCCL if it is absent
+ * Both entry points block until the transform is complete on every device.
+ * _device: d_slabs[g] = device g's [M1][S1/G] column slab, d_rows[g] = its [M1/G][S1] row block (layouts of 2b, packed u32,
+ *          resident on devices[g]).  forward: slabs in (OVERWRITTEN), rows out; inverse: rows in (OVERWRITTEN), slabs out.
+ * _host:   n u64 elements in natural order, in place (x -> X or X -> x); every lane uploads / downloads its own strided share. */
+#define TOYNI_EXCHANGE_PEER_COPY 0
+#define TOYNI_EXCHANGE_RCCL 1
+int toyni_ntt_slab_multi_gpu_device(const int* devices, int ndev, uint32_t n, uint32_t* const* d_slabs, uint32_t* const* d_rows,
+                                    int inverse, int exchange);
+int toyni_ntt_slab_multi_gpu_host(const int* devices, int ndev, uint32_t n, uint64_t* h_data, int inverse, int exchange);
+
 /* Domain points on the device: d_out[i] = shift * w_m^i, i < m (roots_of_unity_domain, src/ntt.rs:69-81, with shift = 1;
  * BabyBearDomain::elements, src/math/domain.rs:61-69) -- the xs that fri_fold and the prover's pointwise steps consume.
  * m: power of two <= the context's n.  The reference's serial multiply chain becomes independent table lookups. */
@@ -197,7 +223,8 @@ int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream);
 int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream);
-int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); ctx unused */
+int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); with a context: also releases what that stream outgrew */
+int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);
 
 /* Per-pass kernel timing for bench.py's roofline object: launches pass p of `batch` transforms `reps` times

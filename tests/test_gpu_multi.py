@@ -1,0 +1,218 @@
+"""GPU tests of round 2's host-facing additions, through the C ABI:
+  * toyni_ntt_slab_multi_gpu_{host,device}: ONE transform over G lanes from one process (include/toyni_hip.h 2c).  The box has one
+    GPU, so the lanes share device 0 -- the exchange-by-copy path; with RCCL the group has one rank (send/recv to self).
+  * per-stream intermediates: one context driven from two streams at once (the async contract; reference src/ntt.rs:128-141
+    serialises nothing and shares d_data)
+  * context-free host entry points after the staging rewrite (fold, Ext fold, Merkle): repeated calls, zero points."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    torch.cuda.init()
+    import toyni_amd
+    assert toyni_amd.gpu_available()
+    return toyni_amd
+
+
+@pytest.mark.parametrize("log_n,lanes", [(11, 1), (12, 2), (13, 4), (16, 8), (20, 1), (20, 4), (21, 8), (22, 2), (24, 8)])
+def test_slab_multi_gpu_host_natural_order(ta, log_n, lanes):
+    n = 1 << log_n
+    x = oracle.splitmix(n, 4100 + log_n + lanes)
+    v = x.copy()
+    ta.ntt_slab_multi_gpu_host(v, [0] * lanes)
+    assert (v == oracle.ntt(x)).all(), "forward"
+    ta.ntt_slab_multi_gpu_host(v, [0] * lanes, inverse=True)
+    assert (v == x).all(), "inverse"
+
+
+def test_slab_multi_gpu_host_matches_single_device_at_2_27(ta):
+    # BASELINE configs[4] at the field's limit (2^28 does not exist), 8 lanes
+    n = 1 << 27
+    x = oracle.splitmix(n, 2727)
+    want = x.copy()
+    ta.ntt.get_or_create_ctx(n).run_host(want, False)
+    v = x.copy()
+    ta.ntt_slab_multi_gpu_host(v, [0] * 8)
+    assert (v == want).all()
+    ta.ntt_slab_multi_gpu_host(v, [0] * 8, inverse=True)
+    assert (v == x).all()
+    ta.ntt.get_or_create_ctx(n).trim()
+
+
+@pytest.mark.parametrize("log_n,lanes", [(16, 2), (22, 8)])
+def test_slab_multi_gpu_device_layouts(ta, log_n, lanes):
+    import torch
+    from toyni_amd import dist as tdist
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    x = oracle.splitmix(n, 4300 + log_n)
+    want = oracle.ntt(x)
+    slabs = [torch.from_numpy(x[tdist.slab_input_index(log_n, lanes, g).numpy()].astype(np.int32)).to(dev) for g in range(lanes)]
+    keep = [t.clone() for t in slabs]
+    rows = [torch.empty(n // lanes, dtype=torch.int32, device=dev) for _ in range(lanes)]
+    torch.cuda.synchronize()
+    ta.ntt_slab_multi_gpu_device(n, [0] * lanes, [t.data_ptr() for t in slabs], [t.data_ptr() for t in rows])
+    for h in range(lanes):
+        idx = tdist.slab_output_index(log_n, lanes, h).numpy().reshape(-1)
+        assert (rows[h].cpu().numpy().view(np.uint32).astype(np.uint64) == want[idx]).all(), f"rows of lane {h}"
+    ta.ntt_slab_multi_gpu_device(n, [0] * lanes, [t.data_ptr() for t in slabs], [t.data_ptr() for t in rows], inverse=True)
+    for g in range(lanes):
+        assert torch.equal(slabs[g], keep[g]), f"slab of lane {g}"
+
+
+def test_slab_multi_gpu_rccl_group_of_one(ta):
+    # the RCCL exchange (dlopen'ed librccl, ncclCommInitAll, grouped send/recv) with the one device of the box: one rank
+    n = 1 << 18
+    x = oracle.splitmix(n, 4400)
+    v = x.copy()
+    ta.ntt_slab_multi_gpu_host(v, [0], exchange=ta.ntt.EXCHANGE_RCCL)
+    assert (v == oracle.ntt(x)).all()
+    ta.ntt_slab_multi_gpu_host(v, [0], inverse=True, exchange=ta.ntt.EXCHANGE_RCCL)
+    assert (v == x).all()
+    with pytest.raises(ta._lib.ToyniError):          # one communicator rank per device: duplicate lanes need the peer-copy form
+        ta.ntt_slab_multi_gpu_host(v, [0, 0], exchange=ta.ntt.EXCHANGE_RCCL)
+
+
+def test_slab_multi_gpu_rejects_bad_arguments(ta):
+    lib = ta._lib.lib
+    v = np.zeros(1 << 16, dtype=np.uint64)
+    devs3 = (ctypes.c_int * 3)(0, 0, 0)
+    assert lib.toyni_ntt_slab_multi_gpu_host(devs3, 3, 1 << 16, v.ctypes.data, 0, 0) == 10006       # lanes not a power of two
+    devs1 = (ctypes.c_int * 1)(0)
+    assert lib.toyni_ntt_slab_multi_gpu_host(devs1, 1, 1 << 10, v.ctypes.data, 0, 0) == 10001       # single-pass size: nothing to split
+    assert lib.toyni_ntt_slab_multi_gpu_host(devs1, 1, 1 << 16, v.ctypes.data, 0, 7) == 10006       # unknown exchange
+    bad = (ctypes.c_int * 1)(99)
+    assert lib.toyni_ntt_slab_multi_gpu_host(bad, 1, 1 << 16, v.ctypes.data, 0, 0) == 10006         # no such device
+    devs16 = (ctypes.c_int * 16)(*([0] * 16))
+    assert lib.toyni_ntt_slab_multi_gpu_host(devs16, 16, 1 << 11, v.ctypes.data, 0, 0) == 10006     # < 32 columns per lane
+
+
+def test_two_streams_on_one_context_interleaved(ta):
+    """two streams on ONE context at n = 2^20, 50 interleaved launches, bit-exact.  Each stream owns its
+    intermediate buffer, so the launches of the two streams may overlap on the device."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    ctx = ta.NttContext(n)
+    xa, xb = oracle.splitmix(n, 51), oracle.splitmix(n, 52)
+    wa, wb = oracle.ntt(xa), oracle.ntt(xb)
+    ta_, tb_ = (torch.from_numpy(v.astype(np.int32)).to(dev) for v in (xa, xb))
+    oa, ob = torch.empty_like(ta_), torch.empty_like(tb_)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for i in range(50):
+        inv = bool(i & 1)                       # forward out of place, then inverse back: both streams keep working sets alive
+        ctx.run_device(oa.data_ptr() if inv else ta_.data_ptr(), ta_.data_ptr() if inv else oa.data_ptr(), 1, inv, stream=s1.cuda_stream)
+        ctx.run_device(ob.data_ptr() if inv else tb_.data_ptr(), tb_.data_ptr() if inv else ob.data_ptr(), 1, inv, stream=s2.cuda_stream)
+    ctx.synchronize(s1.cuda_stream)
+    ctx.synchronize(s2.cuda_stream)
+    assert (oa.cpu().numpy().view(np.uint32) == wa).all() and (ob.cpu().numpy().view(np.uint32) == wb).all()
+    assert (ta_.cpu().numpy().view(np.uint32) == xa).all() and (tb_.cpu().numpy().view(np.uint32) == xb).all()
+    # growing the batch on one stream while the other keeps launching: no hipFree on the enqueue path, results stay exact
+    big = torch.from_numpy(np.concatenate([xa, xb, xa, xb]).astype(np.int32)).to(dev)
+    for i in range(10):
+        ctx.run_device(ta_.data_ptr(), oa.data_ptr(), 1, False, stream=s1.cuda_stream)
+        if i == 3:
+            ctx.run_device(big.data_ptr(), big.data_ptr(), 4, False, stream=s2.cuda_stream)
+    ctx.synchronize(s1.cuda_stream)
+    ctx.synchronize(s2.cuda_stream)
+    got = big.cpu().numpy().view(np.uint32).reshape(4, n)
+    assert (got[0] == wa).all() and (got[1] == wb).all() and (got[3] == wb).all() and (oa.cpu().numpy().view(np.uint32) == wa).all()
+    ctx.trim()
+    ctx.destroy()
+
+
+def test_many_streams_evict_scratch_sets(ta):
+    # more streams than the context keeps buffer sets for (8): the least recently used set is retired, nothing breaks
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1 << 14
+    ctx = ta.NttContext(n)
+    x = oracle.splitmix(n, 77)
+    want = oracle.ntt(x)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    bufs = [torch.from_numpy(x.astype(np.int32)).to(dev) for _ in streams]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for st, b in zip(streams, bufs):
+            ctx.run_device(b.data_ptr(), b.data_ptr(), 1, bool(rnd & 1), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert (b.cpu().numpy().view(np.uint32) == want).all()
+    ctx.destroy()
+
+
+def test_host_fold_staging_repeated_calls_and_zero_points(ta):
+    rng = np.random.default_rng(9)
+    for m in (2, 6, 64, 1 << 12, 1 << 16, 10, 1 << 12):       # growing and shrinking: the staging set is reused
+        e = rng.integers(0, P, m, dtype=np.uint64)
+        xs = rng.integers(1, P, m, dtype=np.uint64)
+        beta = int(rng.integers(0, P))
+        assert (ta.fri_fold(e, xs, beta) == oracle.fri_fold(e, xs, beta)).all(), m
+        e4 = rng.integers(0, P, (m, 4), dtype=np.uint64)
+        b4 = rng.integers(0, P, 4, dtype=np.uint64)
+        assert (ta.fri_fold_ext(e4, xs, b4) == oracle.fri_fold_ext(e4, xs, b4)).all(), m
+    # non-canonical inputs reduce like BabyBear::new (src/babybear.rs:26-30)
+    e = rng.integers(0, 2**63, 256, dtype=np.uint64)
+    xs = rng.integers(1, P, 256, dtype=np.uint64) + np.uint64(P)
+    assert (ta.fri_fold(e, xs, P + 5) == oracle.fri_fold(e % P, xs % P, 5)).all()
+    # a zero point: "Cannot invert zero" (src/babybear.rs:112) -- also when it only appears after reduction, only within xs[0 .. m/2)
+    xs = rng.integers(1, P, 64, dtype=np.uint64)
+    e = rng.integers(0, P, 64, dtype=np.uint64)
+    xs[40] = 0                                                   # beyond m/2: never read (src/math/fri.rs:31-36)
+    assert (ta.fri_fold(e, xs, 3) == oracle.fri_fold(e, np.where(xs == 0, 1, xs), 3)).all()
+    xs[13] = P
+    with pytest.raises(AssertionError, match="Cannot invert zero"):
+        ta.fri_fold(e, xs, 3)
+    with pytest.raises(AssertionError, match="Cannot invert zero"):
+        ta.fri_fold_ext(rng.integers(0, P, (64, 4), dtype=np.uint64), xs, [1, 2, 3, 4])
+
+
+def test_device_fold_xs_isolates_a_zero_point(ta):
+    """in the explicit-point device kernels four points share one Fermat inversion; a zero among them must not
+    zero its neighbours' inverses.  The zero's own inverse is 0 = pow(0, p - 2)."""
+    lib = ta._lib.lib
+    m = 64
+    rng = np.random.default_rng(10)
+    e = rng.integers(0, P, m, dtype=np.uint64)
+    xs = rng.integers(1, P, m // 2, dtype=np.uint64)
+    xs[5] = 0
+    beta = 123456
+    want = oracle.fri_fold(e, np.concatenate([np.where(xs == 0, 1, xs), np.ones(m // 2, dtype=np.uint64)]), beta)
+    a, b = int(e[5]), int(e[5 + m // 2])
+    want[5] = oracle.bb_mul(oracle.bb_add(a, b), (P + 1) // 2)  # x^-1 = 0: only the average survives
+    bufs = []
+    for arr in (e.astype(np.uint32), xs.astype(np.uint32), np.zeros(m // 2, dtype=np.uint32)):
+        p = ctypes.c_void_p()
+        assert lib.toyni_malloc(ctypes.byref(p), arr.nbytes) == 0
+        assert lib.toyni_memcpy_h2d(p, arr.ctypes.data, arr.nbytes) == 0
+        bufs.append(p)
+    assert lib.toyni_fri_fold_xs_device(bufs[0], bufs[1], bufs[2], m, beta, None) == 0
+    out = np.empty(m // 2, dtype=np.uint32)
+    assert lib.toyni_memcpy_d2h(out.ctypes.data, bufs[2], out.nbytes) == 0
+    assert (out == want).all()
+    for p in bufs:
+        lib.toyni_free(p)
+
+
+def test_host_merkle_staging_repeated(ta):
+    rng = np.random.default_rng(11)
+    for n in (1, 3, 1000, 1 << 14, 5):
+        vals = rng.integers(0, P, n, dtype=np.uint64)
+        salts = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        for s in (None, salts):
+            t = ta.MerkleTree(vals, s)
+            assert t.root() == oracle.merkle_commit_values(vals, s)[-1][0].tobytes(), (n, s is None)

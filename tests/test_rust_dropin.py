@@ -33,8 +33,14 @@ def _build_rs_commands():
 
 def test_build_rs_tracks_every_copied_file():
     _, _, rerun = _build_rs_commands()
-    for f in _integration_file_list():
-        assert os.path.basename(f) in rerun, f"rust/build.rs has no rerun-if-changed line for hip/{os.path.basename(f)}"
+    listed = {os.path.basename(f) for f in _integration_file_list()}
+    for f in listed:
+        assert f in rerun, f"rust/build.rs has no rerun-if-changed line for hip/{f}"
+    # and INTEGRATION.md lists every source of the translation unit (csrc/host/ is the C++ mirror, not part of the crate)
+    csrc = os.path.join(ROOT, "toyni_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp", ".h")):
+            assert f in listed, f"toyni_amd/csrc/{f} is missing from INTEGRATION.md section 1 (the crate's hip/ directory would not build)"
 
 
 def test_following_integration_md_produces_a_linkable_archive(tmp_path):

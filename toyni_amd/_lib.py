@@ -84,6 +84,8 @@ SIGNATURES = {
     "toyni_ntt_ctx_first_pass_points": (c_size, [c_void_p]),
     "toyni_ntt_slab_pass_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_slab_relayout_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
+    "toyni_ntt_slab_multi_gpu_device": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_void_p, c_int, c_int]),
+    "toyni_ntt_slab_multi_gpu_host": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_int, c_int]),
     # section 3
     "toyni_fri_fold_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p]),
     "toyni_fri_fold_layers_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
@@ -103,6 +105,7 @@ SIGNATURES = {
     "toyni_narrow_u64_to_u32": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     "toyni_widen_u32_to_u64": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
+    "toyni_ntt_ctx_trim": (c_int, [c_void_p]),
     "toyni_set_device": (c_int, [c_int]),
     "toyni_ntt_profile_passes": (c_int, [c_void_p, c_void_p, c_size, c_int, c_int, ctypes.POINTER(ctypes.c_float), c_void_p]),
     "toyni_microbench": (c_int, [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_u32)]),

@@ -40,11 +40,19 @@
 #define TOYNI_WAIT_VMEM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 // s_waitcnt vmcnt(N): everything but the N youngest VMEM operations has retired (N <= 63, compile-time)
 #define TOYNI_WAIT_VMEM_ALLOW(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 0xF) | (((N) >> 4) << 14))
+// Workgroup barrier that orders LDS traffic only.  Written as inline asm with a "memory" clobber so that the COMPILER keeps
+// every LDS access on its side of the barrier (the s_barrier builtin is IntrNoMem: nothing at IR level would order the next
+// tile's LDS stores against it); no vmcnt drain, unlike __syncthreads().  TOYNI_LDS_BARRIER first waits for this wave's own
+// LDS operations (lgkmcnt), i.e. "my writes have landed"; TOYNI_BARRIER is the bare rendezvous ("everyone has read").
+#define TOYNI_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define TOYNI_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #else
 #define TOYNI_SCHED_FENCE() ((void)0)
 #define TOYNI_PIN(v) ((void)0)
 #define TOYNI_WAIT_VMEM0() ((void)0)
 #define TOYNI_WAIT_VMEM_ALLOW(N) ((void)0)
+#define TOYNI_BARRIER() ((void)0)
+#define TOYNI_LDS_BARRIER() ((void)0)
 #endif
 
 namespace toyni {

@@ -1,0 +1,391 @@
+// Multi-GPU forms of the transform for a SINGLE-PROCESS host (Toyni is one Rust process: src/ntt.rs:128-141,
+// src/fibonacci.rs:99-103).  Included by toyni_hip.hip (one translation unit); declarations in include/toyni_hip.h 2c.
+//
+//   1. toyni_ntt_host_multi_gpu   -- the batched host-slice transform sharded over devices, no exchange;
+//                                    contexts are cached per (device, lane, n) for the life of the process.
+//   2. toyni_ntt_slab_multi_gpu_* -- ONE size-n transform over G devices with ONE exchange (BASELINE
+//                                    configs[4]): slab pass -> exchange of contiguous row blocks -> relayout -> row transforms
+//                                    (the transpose-free form of header section 2b).  The exchange is either
+//                                      * peer copies: every destination pulls its G blocks with hipMemcpyPeerAsync, one copy
+//                                        stream per source so that all incoming xGMI links carry data at once, or
+//                                      * RCCL: one ncclGroupStart / ncclSend+ncclRecv per peer / ncclGroupEnd over communicators
+//                                        from ncclCommInitAll.  librccl (573 MB) is loaded on first use with dlopen, not linked:
+//                                        single-GPU users of this library never pay for it, and a process that already holds an
+//                                        RCCL (PyTorch) shares that copy by SONAME.
+// The multi-PROCESS form of the same algorithm (one rank per GPU, torch.distributed / RCCL all-to-all) is toyni_amd/dist.py;
+// both drive the same device entry points (toyni_ntt_slab_pass_device, toyni_ntt_slab_relayout_device, toyni_ntt_device).
+#pragma once
+#include <dlfcn.h>
+
+// ---- per-(device, lane, n) context cache: process lifetime, never destroyed (src/ntt.rs:128-141) ----
+namespace {
+
+struct CtxKey {
+    int device, lane;
+    uint32_t n;
+    bool operator<(const CtxKey& o) const { return device != o.device ? device < o.device : lane != o.lane ? lane < o.lane : n < o.n; }
+};
+
+int cached_ctx(int device, int lane, uint32_t n, toyni_ntt_ctx** out) {
+    static std::mutex mu;
+    static std::map<CtxKey, toyni_ntt_ctx*> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({device, lane, n});
+    if (it == cache.end()) {
+        toyni_ntt_ctx* c = nullptr;
+        int rc = toyni_ntt_ctx_create(n, device, &c);
+        if (rc) return rc;
+        it = cache.emplace(CtxKey{device, lane, n}, c).first;
+    }
+    *out = it->second;
+    return TOYNI_OK;
+}
+
+// lane index of entry d among the entries that name the same device (a device may be listed more than once)
+int lane_of(const int* devices, int d) {
+    int lane = 0;
+    for (int i = 0; i < d; ++i) lane += devices[i] == devices[d];
+    return lane;
+}
+
+// ---- RCCL, bound at first use ----
+// Plain C declarations of the five entry points used (rccl.h: ncclCommInitAll :236, ncclSend :700, ncclUint32 = 3); the
+// header itself is not included so that the crate's hip/ directory builds without RCCL's include path.
+typedef void* rccl_comm_t;
+struct RcclApi {
+    int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int RCCL_UINT32 = 3;
+
+const RcclApi& rccl() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+        a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+        a.ok = a.CommInitAll && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+        return a;
+    }();
+    return api;
+}
+
+// ---- one transform over G lanes ----
+struct SlabLane {
+    int device = 0;
+    toyni_ntt_ctx* big = nullptr;   // size-n context: slab pass, relayout tables
+    toyni_ntt_ctx* row = nullptr;   // size-S1 context: the row transforms
+    hipStream_t stream = nullptr;   // the lane's compute stream
+    std::vector<hipStream_t> pull;  // one copy stream per source lane (peer-copy exchange)
+    hipEvent_t ready = nullptr;     // "my outgoing blocks are final"
+    std::vector<hipEvent_t> got;    // per source lane: "its block has landed here"
+    uint32_t* d_xchg = nullptr;     // [G][r][w] pieces: landing buffer (forward) / outgoing buffer (inverse); n / G words
+    // host form only
+    uint32_t* d_slab = nullptr;     // [M1][w]
+    uint32_t* d_rows = nullptr;     // [r][S1]
+    uint64_t* d_stage = nullptr;    // n / G u64
+    rccl_comm_t comm = nullptr;
+};
+
+struct SlabGroup {
+    std::mutex mu;                  // one transform at a time per group (blocking entry points)
+    std::vector<SlabLane> lanes;
+    uint32_t n = 0;
+    size_t m1 = 0, s1 = 0;
+    bool rccl_ready = false, host_buffers = false;
+};
+
+#define MG_TRY(expr) do { int _rc = (int)(expr); if (_rc) return _rc; } while (0)
+
+int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
+    static std::mutex mu;
+    static std::map<std::pair<std::vector<int>, uint32_t>, SlabGroup*> groups;  // process lifetime
+    std::lock_guard<std::mutex> lk(mu);
+    const std::vector<int> key(devices, devices + ndev);
+    auto it = groups.find({key, n});
+    if (it != groups.end()) { *out = it->second; return TOYNI_OK; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    for (int d = 0; d < ndev; ++d) if (devices[d] < 0 || devices[d] >= count) return TOYNI_E_RANGE;
+    SlabGroup* g = new SlabGroup();
+    g->n = n;
+    g->lanes.resize((size_t)ndev);
+    for (int d = 0; d < ndev; ++d) {
+        SlabLane& L = g->lanes[(size_t)d];
+        L.device = devices[d];
+        const int lane = lane_of(devices, d);
+        MG_TRY(cached_ctx(L.device, lane, n, &L.big));
+        if (d == 0) {
+            g->m1 = toyni_ntt_ctx_first_pass_points(L.big);
+            if (!g->m1) return TOYNI_E_INVALID_SIZE;  // n <= 1024: a single pass, nothing to split
+            g->s1 = (size_t)n / g->m1;
+            if (g->s1 / (size_t)ndev < 32 || g->m1 < (size_t)ndev) return TOYNI_E_RANGE;
+        }
+        MG_TRY(cached_ctx(L.device, lane, (uint32_t)g->s1, &L.row));
+        DeviceGuard guard(L.device);
+        MG_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        MG_TRY(hipEventCreateWithFlags(&L.ready, hipEventDisableTiming));
+        L.pull.resize((size_t)ndev);
+        L.got.resize((size_t)ndev);
+        for (int sidx = 0; sidx < ndev; ++sidx) {
+            MG_TRY(hipStreamCreateWithFlags(&L.pull[(size_t)sidx], hipStreamNonBlocking));
+            MG_TRY(hipEventCreateWithFlags(&L.got[(size_t)sidx], hipEventDisableTiming));
+        }
+        MG_TRY(hipMalloc((void**)&L.d_xchg, ((size_t)n / (size_t)ndev) * sizeof(uint32_t)));
+        // direct xGMI access between the lanes' devices (an error here only means "already enabled" or "same device")
+        for (int p = 0; p < ndev; ++p)
+            if (devices[p] != L.device && hipDeviceEnablePeerAccess(devices[p], 0) != hipSuccess) (void)hipGetLastError();
+    }
+    groups.emplace(std::make_pair(key, n), g);
+    *out = g;
+    return TOYNI_OK;
+}
+
+int slab_group_rccl(SlabGroup* g) {
+    if (g->rccl_ready) return TOYNI_OK;
+    const RcclApi& api = rccl();
+    if (!api.ok) return TOYNI_E_NO_RCCL;
+    const size_t G = g->lanes.size();
+    std::vector<int> devs(G);
+    for (size_t d = 0; d < G; ++d) devs[d] = g->lanes[d].device;
+    for (size_t a = 0; a < G; ++a)
+        for (size_t b = a + 1; b < G; ++b)
+            if (devs[a] == devs[b]) return TOYNI_E_RANGE;  // one communicator rank per device: no duplicate lanes with RCCL
+    std::vector<rccl_comm_t> comms(G, nullptr);
+    if (api.CommInitAll(comms.data(), (int)G, devs.data()) != 0) return TOYNI_E_RCCL;
+    for (size_t d = 0; d < G; ++d) g->lanes[d].comm = comms[d];
+    g->rccl_ready = true;
+    return TOYNI_OK;
+}
+
+// Block h of src lane g's [G][r][w] view -> piece g of dst lane h's [G][r][w] view; `blk` = r * w words.
+//   send(g) / recv(h): base pointers of the lane's outgoing / landing buffers
+// On return every lane's compute stream is ordered after the arrival of all its pieces.
+template <class SendPtr, class RecvPtr>
+int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPtr&& recv) {
+    const size_t G = g->lanes.size();
+    if (exchange == TOYNI_EXCHANGE_RCCL) {
+        const RcclApi& api = rccl();
+        if (api.GroupStart() != 0) return TOYNI_E_RCCL;
+        for (size_t a = 0; a < G; ++a) {
+            SlabLane& L = g->lanes[a];
+            for (size_t b = 0; b < G; ++b) {  // in stream order on the lane's compute stream: no events needed
+                if (api.Send(send(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;
+                if (api.Recv(recv(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;
+            }
+        }
+        if (api.GroupEnd() != 0) return TOYNI_E_RCCL;
+        return TOYNI_OK;
+    }
+    for (size_t a = 0; a < G; ++a) {  // every producer marks its outgoing blocks final
+        DeviceGuard guard(g->lanes[a].device);
+        MG_TRY(hipEventRecord(g->lanes[a].ready, g->lanes[a].stream));
+    }
+    for (size_t h = 0; h < G; ++h) {  // every destination pulls, one copy stream per source: all incoming links at once
+        SlabLane& D = g->lanes[h];
+        DeviceGuard guard(D.device);
+        for (size_t a = 0; a < G; ++a) {
+            SlabLane& S = g->lanes[a];
+            hipStream_t cs = D.pull[a];
+            MG_TRY(hipStreamWaitEvent(cs, S.ready, 0));
+            if (S.device == D.device)
+                MG_TRY(hipMemcpyAsync(recv(h) + a * blk, send(a) + h * blk, blk * sizeof(uint32_t), hipMemcpyDeviceToDevice, cs));
+            else
+                MG_TRY(hipMemcpyPeerAsync(recv(h) + a * blk, D.device, send(a) + h * blk, S.device, blk * sizeof(uint32_t), cs));
+            MG_TRY(hipEventRecord(D.got[a], cs));
+            MG_TRY(hipStreamWaitEvent(D.stream, D.got[a], 0));
+        }
+    }
+    return TOYNI_OK;
+}
+
+int slab_run(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bool inverse, int exchange) {
+    const size_t G = g->lanes.size();
+    const size_t w = g->s1 / G, r = g->m1 / G, blk = r * w;
+    if (exchange == TOYNI_EXCHANGE_RCCL) MG_TRY(slab_group_rccl(g));
+    else if (exchange != TOYNI_EXCHANGE_PEER_COPY) return TOYNI_E_RANGE;
+    if (!inverse) {
+        for (size_t a = 0; a < G; ++a) {  // M1-point column transforms x w_n^(j' k1), in place on the slab
+            SlabLane& L = g->lanes[a];
+            MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 0, L.stream));
+        }
+        // row block h of a slab (k1 in lane h's chunk) is contiguous: no packing
+        MG_TRY(slab_exchange(g, blk, exchange, [&](size_t a) { return d_slabs[a]; }, [&](size_t h) { return g->lanes[h].d_xchg; }));
+        for (size_t h = 0; h < G; ++h) {
+            SlabLane& L = g->lanes[h];
+            MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg, d_rows[h], r, h * r, G, 0, L.stream));  // pieces -> rows [r][S1]
+            MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 0, L.stream));                         // size-S1 transforms over j'
+        }
+    } else {
+        for (size_t h = 0; h < G; ++h) {
+            SlabLane& L = g->lanes[h];
+            MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 1, L.stream));                         // inverse size-S1, scaled by 1/S1
+            MG_TRY(toyni_ntt_slab_relayout_device(L.big, d_rows[h], L.d_xchg, r, h * r, G, 1, L.stream));  // x w_n^-(k1 j'), rows -> pieces
+        }
+        MG_TRY(slab_exchange(g, blk, exchange, [&](size_t h) { return g->lanes[h].d_xchg; }, [&](size_t a) { return d_slabs[a]; }));
+        for (size_t a = 0; a < G; ++a) {
+            SlabLane& L = g->lanes[a];
+            MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 1, L.stream));  // closing inverse column transforms, 1/M1
+        }
+    }
+    return TOYNI_OK;
+}
+
+int slab_sync(SlabGroup* g) {
+    int rc = TOYNI_OK;
+    for (SlabLane& L : g->lanes) {
+        DeviceGuard guard(L.device);
+        hipError_t e = hipStreamSynchronize(L.stream);
+        if (e != hipSuccess && rc == TOYNI_OK) rc = (int)e;
+    }
+    return rc;
+}
+
+// [R][C] -> [C][R] through a 32 x 33 LDS tile, converting the element type (u32 -> u64 widens, u64 -> u32 reduces like
+// BabyBear::new): the natural-order <-> row-block re-layout of the host form, on the device (PCIe then moves whole runs)
+template <class IN, class OUT>
+__global__ void __launch_bounds__(256) transpose_convert_kernel(const IN* __restrict__ in, OUT* __restrict__ out, uint32_t R, uint32_t C) {
+    __shared__ uint32_t tile[32][33];
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
+    const uint32_t tiles_c = (C + 31u) / 32u;
+    const uint64_t ntiles = (uint64_t)tiles_c * ((R + 31u) / 32u);
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t r0 = (uint32_t)(t / tiles_c) * 32u, c0 = (uint32_t)(t % tiles_c) * 32u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t rr = r0 + ty + 8u * k, cc = c0 + tx;
+            if (rr < R && cc < C) tile[ty + 8u * k][tx] = (uint32_t)(in[(uint64_t)rr * C + cc] % BB_P);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t cc = c0 + ty + 8u * k, rr = r0 + tx;
+            if (rr < R && cc < C) out[(uint64_t)cc * R + rr] = tile[tx][ty + 8u * k];
+        }
+        __syncthreads();
+    }
+}
+
+int slab_host_buffers(SlabGroup* g) {
+    if (g->host_buffers) return TOYNI_OK;
+    const size_t per = (size_t)g->n / g->lanes.size();
+    for (SlabLane& L : g->lanes) {
+        DeviceGuard guard(L.device);
+        MG_TRY(hipMalloc((void**)&L.d_slab, per * sizeof(uint32_t)));
+        MG_TRY(hipMalloc((void**)&L.d_rows, per * sizeof(uint32_t)));
+        MG_TRY(hipMalloc((void**)&L.d_stage, per * sizeof(uint64_t)));
+    }
+    g->host_buffers = true;
+    return TOYNI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Batched host-slice transform over several GPUs from one host process: contiguous shards, one host thread per entry,
+// cached contexts (the first call per (device, lane, n) builds them), no exchange.
+int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t* h_data, size_t batch, int inverse) {
+    if (!devices || !h_data) return TOYNI_E_NULL;
+    if (ndev < 1) return TOYNI_E_RANGE;
+    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    std::vector<int> status((size_t)ndev, TOYNI_OK);
+    std::vector<std::thread> workers;
+    const size_t base = batch / (size_t)ndev, rem = batch % (size_t)ndev;
+    size_t start = 0;
+    for (int d = 0; d < ndev; ++d) {
+        const size_t count = base + ((size_t)d < rem ? 1 : 0);
+        const size_t first = start;
+        start += count;
+        if (count == 0) continue;
+        workers.emplace_back([&, d, first, count]() {
+            toyni_ntt_ctx* ctx = nullptr;
+            int rc = cached_ctx(devices[d], lane_of(devices, d), n, &ctx);
+            if (rc == TOYNI_OK) rc = toyni_ntt_host(ctx, h_data + first * (size_t)n, count, inverse);
+            status[(size_t)d] = rc;
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int rc : status) if (rc != TOYNI_OK) return rc;
+    return TOYNI_OK;
+}
+
+int toyni_ntt_slab_multi_gpu_device(const int* devices, int ndev, uint32_t n, uint32_t* const* d_slabs, uint32_t* const* d_rows,
+                                    int inverse, int exchange) {
+    if (!devices || !d_slabs || !d_rows) return TOYNI_E_NULL;
+    if (ndev < 1 || (ndev & (ndev - 1))) return TOYNI_E_RANGE;
+    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    for (int d = 0; d < ndev; ++d) if (!d_slabs[d] || !d_rows[d]) return TOYNI_E_NULL;
+    SlabGroup* g = nullptr;
+    MG_TRY(slab_group(devices, ndev, n, &g));
+    std::lock_guard<std::mutex> lk(g->mu);
+    int rc = slab_run(g, d_slabs, d_rows, inverse != 0, exchange);
+    const int rs = slab_sync(g);
+    return rc ? rc : rs;
+}
+
+// Host slice in natural order, in place: n u64 elements.  Per lane: strided upload of its column slab (forward) or its
+// row block (inverse), the device form above, and the mirror-image download; the natural-order <-> row-block transposition
+// runs on the device, so PCIe moves runs of S1 / G (slab) or M1 / G (rows) elements.
+int toyni_ntt_slab_multi_gpu_host(const int* devices, int ndev, uint32_t n, uint64_t* h_data, int inverse, int exchange) {
+    if (!devices || !h_data) return TOYNI_E_NULL;
+    if (ndev < 1 || (ndev & (ndev - 1))) return TOYNI_E_RANGE;
+    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    SlabGroup* g = nullptr;
+    MG_TRY(slab_group(devices, ndev, n, &g));
+    std::lock_guard<std::mutex> lk(g->mu);
+    MG_TRY(slab_host_buffers(g));
+    const size_t G = g->lanes.size(), m1 = g->m1, s1 = g->s1, w = s1 / G, r = m1 / G, per = (size_t)n / G;
+    std::vector<uint32_t*> slabs(G), rows(G);
+    for (size_t a = 0; a < G; ++a) { slabs[a] = g->lanes[a].d_slab; rows[a] = g->lanes[a].d_rows; }
+    for (size_t a = 0; a < G; ++a) {
+        SlabLane& L = g->lanes[a];
+        DeviceGuard guard(L.device);
+        if (!inverse) {
+            // slab [M1][w]: element (j1, c) = x[j1 S1 + a w + c]
+            MG_TRY(hipMemcpy2DAsync(L.d_stage, w * sizeof(uint64_t), h_data + a * w, s1 * sizeof(uint64_t), w * sizeof(uint64_t), m1,
+                                    hipMemcpyHostToDevice, L.stream));
+            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint64_t*)L.d_stage, L.d_slab, per);
+        } else {
+            // rows [r][S1]: element (rr, k') = X[(a r + rr) + M1 k'] -> upload [S1][r] runs, transpose on the device
+            MG_TRY(hipMemcpy2DAsync(L.d_stage, r * sizeof(uint64_t), h_data + a * r, m1 * sizeof(uint64_t), r * sizeof(uint64_t), s1,
+                                    hipMemcpyHostToDevice, L.stream));
+            hipLaunchKernelGGL((transpose_convert_kernel<uint64_t, uint32_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
+                               (const uint64_t*)L.d_stage, L.d_rows, (uint32_t)s1, (uint32_t)r);
+        }
+        MG_TRY(hipGetLastError());
+    }
+    int rc = slab_run(g, slabs.data(), rows.data(), inverse != 0, exchange);
+    if (rc) { (void)slab_sync(g); return rc; }
+    for (size_t a = 0; a < G; ++a) {
+        SlabLane& L = g->lanes[a];
+        DeviceGuard guard(L.device);
+        if (!inverse) {
+            hipLaunchKernelGGL((transpose_convert_kernel<uint32_t, uint64_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
+                               (const uint32_t*)L.d_rows, L.d_stage, (uint32_t)r, (uint32_t)s1);
+            MG_TRY(hipGetLastError());
+            MG_TRY(hipMemcpy2DAsync(h_data + a * r, m1 * sizeof(uint64_t), L.d_stage, r * sizeof(uint64_t), r * sizeof(uint64_t), s1,
+                                    hipMemcpyDeviceToHost, L.stream));
+        } else {
+            hipLaunchKernelGGL(widen_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint32_t*)L.d_slab, L.d_stage, per);
+            MG_TRY(hipGetLastError());
+            MG_TRY(hipMemcpy2DAsync(h_data + a * w, s1 * sizeof(uint64_t), L.d_stage, w * sizeof(uint64_t), w * sizeof(uint64_t), m1,
+                                    hipMemcpyDeviceToHost, L.stream));
+        }
+    }
+    return slab_sync(g);
+}
+
+}  // extern "C"
+#undef MG_TRY

@@ -86,13 +86,12 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
                 inraw = P::in_seed_issue(a, tn, tid);
             }
             TOYNI_SCHED_FENCE();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
-            __builtin_amdgcn_s_barrier();
+            TOYNI_LDS_BARRIER();  // this wave's LDS writes have landed; then the rendezvous
             TOYNI_SCHED_FENCE();
             P::step2(a, t, tid, lds, seeds, uni);
             if (!more) break;
             TOYNI_SCHED_FENCE();
-            __builtin_amdgcn_s_barrier();  // every wave has its step-2 LDS reads in registers before the tile is overwritten
+            TOYNI_BARRIER();  // every wave has its step-2 LDS reads in registers before the tile is overwritten
             TOYNI_SCHED_FENCE();
             t = tn;
             v = vn;
@@ -126,18 +125,16 @@ __global__ void __launch_bounds__(L::T, 4) ntt_lds_kernel(const LdsArgs g, const
         const bool more = next < ntiles;  // uniform
         if (more) L::loadA(g, next, tid, x);  // prefetch
         TOYNI_SCHED_FENCE();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        TOYNI_LDS_BARRIER();
         TOYNI_SCHED_FENCE();
         L::phaseB(tid, lds, lds_tw1);
         TOYNI_SCHED_FENCE();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        TOYNI_LDS_BARRIER();
         TOYNI_SCHED_FENCE();
         L::phaseC(g, tile, tid, lds, uni);
         if (!more) break;
         TOYNI_SCHED_FENCE();
-        __builtin_amdgcn_s_barrier();  // phase C's LDS reads are in registers before the tile is overwritten
+        TOYNI_BARRIER();  // phase C's LDS reads are in registers before the tile is overwritten
         TOYNI_SCHED_FENCE();
         tile = next;
     }
@@ -146,6 +143,19 @@ __global__ void __launch_bounds__(L::T, 4) ntt_lds_kernel(const LdsArgs g, const
 __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = narrow_u64(in[i]);
+}
+
+// narrow + "Cannot invert zero" check of the fold's points (src/babybear.rs:112): *flag becomes 1 if any reduced point is 0
+__global__ void __launch_bounds__(256) narrow_nonzero_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count,
+                                                              uint32_t* __restrict__ flag) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool any_zero = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t v = narrow_u64(in[i]);
+        out[i] = v;
+        any_zero |= v == 0u;
+    }
+    if (any_zero) atomicOr(flag, 1u);
 }
 
 __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t count) {
@@ -265,19 +275,25 @@ __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __rest
     const uint64_t groups = (half + 3) / 4;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
         uint32_t x[4], pre[4];
+        bool zero[4];
         uint32_t acc = 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t i = 4 * q + j;
             x[j] = i < half ? xs[i] : 1u;
+            // a zero point is kept OUT of the shared product (it would zero the inverses of its three neighbours): it
+            // rides along as 1 and its own inverse is forced to 0 = pow(0, p-2), what BabyBear::inverse would compute
+            // without its zero assert (src/babybear.rs:111-114); the host forms report TOYNI_E_ZERO_INVERSE instead
+            zero[j] = x[j] == 0u;
+            if (zero[j]) x[j] = 1u;
             pre[j] = acc;                       // product of x[0..j)
             acc = bb_mul_plain(acc, x[j]);
         }
-        uint32_t inv = bb_inv_dev(acc);         // 0 -> 0, like pow(0, p-2)
+        uint32_t inv = bb_inv_dev(acc);         // acc != 0 by construction
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
             const uint64_t i = 4 * q + j;
-            const uint32_t xinv = bb_mul_plain(inv, pre[j]);
+            const uint32_t xinv = zero[j] ? 0u : bb_mul_plain(inv, pre[j]);
             inv = bb_mul_plain(inv, x[j]);
             if (i < half) {
                 const uint32_t a = evals[i], b = evals[i + half];
@@ -319,11 +335,14 @@ __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __res
     const uint64_t groups = (half + 3) / 4;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
         uint32_t x[4], pre[4];
+        bool zero[4];
         uint32_t acc = 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t i = 4 * q + j;
             x[j] = i < half ? xs[i] : 1u;
+            zero[j] = x[j] == 0u;               // see fri_fold_xs_kernel
+            if (zero[j]) x[j] = 1u;
             pre[j] = acc;
             acc = bb_mul_plain(acc, x[j]);
         }
@@ -331,7 +350,7 @@ __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __res
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
             const uint64_t i = 4 * q + j;
-            const uint32_t xinv = bb_mul_plain(inv, pre[j]);
+            const uint32_t xinv = zero[j] ? 0u : bb_mul_plain(inv, pre[j]);
             inv = bb_mul_plain(inv, x[j]);
             if (i < half) {
                 const uint4 a = evals[i], b = evals[i + half];
@@ -439,14 +458,27 @@ struct toyni_ntt_ctx {
     hipStream_t stream = nullptr;
     uint32_t* d_fwd = nullptr;
     uint32_t* d_inv = nullptr;
-    uint32_t* d_work = nullptr;      // intermediate passes (reference: NttCtx::d_data, cuda/ntt_kernel.cu:205)
-    size_t work_words = 0;
-    uint32_t* d_data32 = nullptr;    // packed copy for the host / u64 entry points
-    size_t data32_words = 0;
-    uint64_t* d_stage64 = nullptr;   // H2D / D2H staging on the reference's u64 layout
-    size_t stage64_elems = 0;
-    uint32_t* d_lde32 = nullptr;     // compact coefficient vector of toyni_lde_host
-    size_t lde32_words = 0;
+    // Intermediates (the reference keeps ONE shared NttCtx::d_data, cuda/ntt_kernel.cu:205 -- the race of SURVEY.md F8).
+    // Here every stream that carries calls of this context has its own set, so calls enqueued on different streams
+    // never share a buffer and calls on one stream are ordered by the stream: no cross-stream hazard, nothing to wait for.
+    struct Scratch {
+        uint32_t* d_work = nullptr;      // intermediate of multi-pass transforms
+        size_t work_words = 0;
+        uint32_t* d_data32 = nullptr;    // packed copy for the host / u64 / Ext entry points
+        size_t data32_words = 0;
+        uint64_t* d_stage64 = nullptr;   // H2D / D2H staging on the reference's u64 layout
+        size_t stage64_elems = 0;
+        uint32_t* d_lde32 = nullptr;     // compact coefficient vectors of the LDE entry points
+        size_t lde32_words = 0;
+        uint64_t tick = 0;               // last use (eviction order)
+    };
+    std::map<hipStream_t, Scratch> scratch;
+    uint64_t tick = 0;
+    // Buffers that were outgrown or evicted.  They may still be read by kernels in flight, and hipFree is a device-wide
+    // synchronisation, so nothing is freed on an enqueue path: a retired buffer is freed after a synchronisation of the
+    // stream it belonged to (blocking host entry points, toyni_stream_synchronize), by toyni_ntt_ctx_trim, or at destroy.
+    struct Retired { void* ptr; hipStream_t stream; bool stream_known; };
+    std::vector<Retired> retired;
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
@@ -468,12 +500,49 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-int grow(void** buf, size_t* have, size_t need, size_t elem_bytes) {
+constexpr size_t MAX_SCRATCH_STREAMS = 8;
+
+void retire_scratch(toyni_ntt_ctx* c, toyni_ntt_ctx::Scratch& sc, hipStream_t s, bool stream_known) {
+    for (void* p : {(void*)sc.d_work, (void*)sc.d_data32, (void*)sc.d_stage64, (void*)sc.d_lde32})
+        if (p) c->retired.push_back({p, s, stream_known});
+    sc = toyni_ntt_ctx::Scratch();
+}
+
+// the scratch set of stream s (caller holds c->mu).  At most MAX_SCRATCH_STREAMS sets are kept: the least recently used
+// one is retired (its stream may no longer exist, so those buffers wait for toyni_ntt_ctx_trim / destroy).
+toyni_ntt_ctx::Scratch& scratch_for(toyni_ntt_ctx* c, hipStream_t s) {
+    auto it = c->scratch.find(s);
+    if (it == c->scratch.end()) {
+        if (c->scratch.size() >= MAX_SCRATCH_STREAMS) {
+            auto lru = c->scratch.begin();
+            for (auto j = c->scratch.begin(); j != c->scratch.end(); ++j)
+                if (j->first != c->stream && (lru->first == c->stream || j->second.tick < lru->second.tick)) lru = j;
+            retire_scratch(c, lru->second, lru->first, false);
+            c->scratch.erase(lru);
+        }
+        it = c->scratch.emplace(s, toyni_ntt_ctx::Scratch()).first;
+    }
+    it->second.tick = ++c->tick;
+    return it->second;
+}
+
+// grow-only; the outgrown buffer is retired, not freed (no hipFree -- a device-wide sync -- on an enqueue path)
+int grow(toyni_ntt_ctx* c, hipStream_t s, void** buf, size_t* have, size_t need, size_t elem_bytes) {
     if (*have >= need) return 0;
-    if (*buf) { HIPCHK(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    if (*buf) { c->retired.push_back({*buf, s, true}); *buf = nullptr; *have = 0; }
     HIPCHK(hipMalloc(buf, need * elem_bytes));
     *have = need;
     return 0;
+}
+
+// after stream s has been synchronised by the caller: nothing enqueued on it can still touch what it retired
+void reclaim_after_sync(toyni_ntt_ctx* c, hipStream_t s) {
+    size_t keep = 0;
+    for (auto& r : c->retired) {
+        if (r.stream_known && r.stream == s) (void)hipFree(r.ptr);
+        else c->retired[keep++] = r;
+    }
+    c->retired.resize(keep);
 }
 
 int grid_for(size_t items, int block = 256) {
@@ -567,6 +636,7 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u,
                       int lde_log = 0) {
     if (batch == 0) return 0;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     const size_t n = c->n;
     const size_t n_in = n >> lde_log;  // lde_log > 0: the input holds the leading n >> lde_log words of every transform
     CosetTables cs;
@@ -615,17 +685,17 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (chunk > batch) chunk = batch;
     }
     if (c->plan.npasses > 1) {
-        int rc = grow((void**)&c->d_work, &c->work_words, chunk * n, sizeof(uint32_t));
+        int rc = grow(c, s, (void**)&sc.d_work, &sc.work_words, chunk * n, sizeof(uint32_t));
         if (rc) return rc;
     }
     const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
     // streaming launches (footprint well beyond the 256 MiB Infinity Cache) take the non-temporal kernels
-    const bool nt = lde_log == 0 && (uint64_t)batch * n * sizeof(uint32_t) >= nt_min_bytes();
+    const bool nt = lde_log == 0 && (uint64_t)chunk * n * sizeof(uint32_t) >= nt_min_bytes();  // footprint of ONE launch
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
         int pass_index = 0;
-        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n_in, c->d_work, d_out + b0 * n, nb,
+        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb,
                                 [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
                                     using P = decltype(pass);
                                     constexpr int LZ = decltype(lzc)::value;
@@ -666,6 +736,45 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out) {
     return 0;
 }
 
+// Device-side staging of the context-free host-slice entry points (toyni_fri_fold_host, toyni_fri_fold_ext_host,
+// toyni_merkle_commit_host): one grow-only set of buffers and one stream per device for the life of the process, so a call
+// costs copies and kernels, not hipMalloc / hipFree pairs; the u64 -> u32 narrowing (and the zero-point check of the fold)
+// runs on the device, not in a host loop.  One call at a time per device (mutex): these are blocking calls.
+struct HostStage {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    void* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[5] = {0, 0, 0, 0, 0};
+    uint32_t* d_flag = nullptr;
+};
+
+int host_stage_acquire(HostStage** out, int* device) {
+    static std::mutex reg_mu;
+    static std::map<int, HostStage*> reg;  // never freed: process lifetime, like the reference's context cache (src/ntt.rs:128-141)
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    HIPCHK(hipGetDevice(device));
+    std::lock_guard<std::mutex> lk(reg_mu);
+    HostStage*& st = reg[*device];
+    if (!st) {
+        st = new HostStage();
+        hipError_t e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&st->d_flag, sizeof(uint32_t));
+        if (e != hipSuccess) { delete st; st = nullptr; reg.erase(*device); return (int)e; }
+    }
+    *out = st;
+    return TOYNI_OK;
+}
+
+int host_stage_reserve(HostStage* st, int slot, size_t bytes) {
+    if (st->cap[slot] >= bytes) return 0;
+    HIPCHK(hipStreamSynchronize(st->stream));  // blocking entry points: the stream is idle here anyway
+    if (st->buf[slot]) { HIPCHK(hipFree(st->buf[slot])); st->buf[slot] = nullptr; st->cap[slot] = 0; }
+    HIPCHK(hipMalloc(&st->buf[slot], bytes));
+    st->cap[slot] = bytes;
+    return 0;
+}
+
 bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
 int ilog2(size_t v) { int l = 0; while (((size_t)1 << l) < v) ++l; return l; }
 
@@ -685,6 +794,8 @@ const char* toyni_error_string(int status) {
         case TOYNI_E_NO_DEVICE: return "no HIP device available";
         case TOYNI_E_ZERO_INVERSE: return "Cannot invert zero";
         case TOYNI_E_RANGE: return "argument out of range";
+        case TOYNI_E_NO_RCCL: return "librccl could not be loaded (RCCL exchange requested)";
+        case TOYNI_E_RCCL: return "an RCCL call failed";
         default: return hipGetErrorString((hipError_t)status);
     }
 }
@@ -735,10 +846,9 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
         (void)hipFree(c->d_fwd);
         (void)hipFree(c->d_inv);
-        (void)hipFree(c->d_work);
-        (void)hipFree(c->d_data32);
-        (void)hipFree(c->d_stage64);
-        (void)hipFree(c->d_lde32);
+        (void)hipDeviceSynchronize();  // user streams may still carry this context's kernels
+        for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
+        for (auto& r : c->retired) (void)hipFree(r.ptr);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
         (void)hipFree(c->d_ones);
         for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -846,18 +956,20 @@ int toyni_lde_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeffs, u
     while (compact < ncoeffs) compact <<= 1;
     const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
     hipStream_t s = c->stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
-    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, n, sizeof(uint64_t)))) return rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, n, sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, compact, sizeof(uint32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_stage64, h_coeffs, ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(ncoeffs)), dim3(256), 0, s, c->d_stage64, c->d_lde32, ncoeffs);
-    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(c->d_lde32 + ncoeffs, 0, (compact - ncoeffs) * sizeof(uint32_t), s));
-    if ((rc = enqueue_lde(c, c->d_lde32, c->d_data32, 1, log_blowup, (uint32_t)shift, s))) return rc;
-    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    if ((rc = grow(c, s, (void**)&sc.d_stage64, &sc.stage64_elems, n, sizeof(uint64_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, n, sizeof(uint32_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, compact, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(sc.d_stage64, h_coeffs, ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(ncoeffs)), dim3(256), 0, s, sc.d_stage64, sc.d_lde32, ncoeffs);
+    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(sc.d_lde32 + ncoeffs, 0, (compact - ncoeffs) * sizeof(uint32_t), s));
+    if ((rc = enqueue_lde(c, sc.d_lde32, sc.d_data32, 1, log_blowup, (uint32_t)shift, s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, c->d_stage64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_out, sc.d_stage64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    reclaim_after_sync(c, s);
     return TOYNI_OK;
 }
 
@@ -866,13 +978,14 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int i
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     const size_t total = batch * (size_t)c->n;
     if (!total) return TOYNI_OK;
-    int rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t));
+    int rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, total, sizeof(uint32_t));
     if (rc) return rc;
-    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_data, c->d_data32, total);
-    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s))) return rc;
-    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_data32, d_data, total);
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_data, sc.d_data32, total);
+    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, batch, inverse != 0, s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, sc.d_data32, d_data, total);
     return (int)hipGetLastError();
 }
 
@@ -884,49 +997,22 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
     const size_t total = batch * (size_t)c->n;
     if (!total) return TOYNI_OK;
     hipStream_t s = c->stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
-    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, total, sizeof(uint64_t)))) return rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));  // cuda/ntt_kernel.cu:254
-    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_stage64, c->d_data32, total);
-    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, batch, inverse != 0, s, shift))) return rc;
-    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, c->d_data32, c->d_stage64, total);
+    if ((rc = grow(c, s, (void**)&sc.d_stage64, &sc.stage64_elems, total, sizeof(uint64_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, total, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(sc.d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));  // cuda/ntt_kernel.cu:254
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, sc.d_stage64, sc.d_data32, total);
+    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, batch, inverse != 0, s, shift))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, total);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_data, c->d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));  // cuda/ntt_kernel.cu:267
+    HIPCHK(hipMemcpyAsync(h_data, sc.d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));  // cuda/ntt_kernel.cu:267
     HIPCHK(hipStreamSynchronize(s));
+    reclaim_after_sync(c, s);
     return TOYNI_OK;
 }
 
 int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse) { return host_transform(c, h_data, batch, 1u, inverse); }
-
-// Single-process multi-GPU form of the batched host-slice transform (for a host like Toyni, which is one process):
-// the batch is sharded contiguously over the listed devices, one host thread + one context per device, no collective.
-// (The benchmark's scaling runs use one PROCESS per GPU instead: bench.py / toyni_amd/dist.py.)
-int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t* h_data, size_t batch, int inverse) {
-    if (!devices || !h_data) return TOYNI_E_NULL;
-    if (ndev < 1) return TOYNI_E_RANGE;
-    if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
-    std::vector<int> status((size_t)ndev, TOYNI_OK);
-    std::vector<std::thread> workers;
-    const size_t base = batch / (size_t)ndev, rem = batch % (size_t)ndev;
-    size_t start = 0;
-    for (int d = 0; d < ndev; ++d) {
-        const size_t count = base + ((size_t)d < rem ? 1 : 0);
-        const size_t first = start;
-        start += count;
-        workers.emplace_back([&, d, first, count]() {
-            if (count == 0) return;
-            toyni_ntt_ctx* ctx = nullptr;
-            int rc = toyni_ntt_ctx_create(n, devices[d], &ctx);
-            if (rc == TOYNI_OK) rc = toyni_ntt_host(ctx, h_data + first * (size_t)n, count, inverse);
-            (void)toyni_ntt_ctx_destroy(ctx);
-            status[(size_t)d] = rc;
-        });
-    }
-    for (auto& w : workers) w.join();
-    for (int rc : status) if (rc != TOYNI_OK) return rc;
-    return TOYNI_OK;
-}
 
 // fft_ext / ifft_ext (src/math/domain.rs:129-151): one call, one PCIe round trip, the four coordinate transforms as ONE batch of 4
 int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int inverse) {
@@ -937,16 +1023,18 @@ int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int i
     DeviceGuard guard(c->device);
     const size_t n = c->n, total = 4 * n;
     hipStream_t s = c->stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
-    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, total, sizeof(uint64_t)))) return rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, total, sizeof(uint32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_stage64, c->d_data32, n, n);
-    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, (uint32_t)shift))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    if ((rc = grow(c, s, (void**)&sc.d_stage64, &sc.stage64_elems, total, sizeof(uint64_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, total, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(sc.d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_stage64, sc.d_data32, n, n);
+    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, 4, inverse != 0, s, (uint32_t)shift))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_data, c->d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_data, sc.d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    reclaim_after_sync(c, s);
     return TOYNI_OK;
 }
 
@@ -958,11 +1046,12 @@ int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int
     DeviceGuard guard(c->device);
     const size_t n = c->n;
     hipStream_t s = (hipStream_t)stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, c->d_data32, n, n);
-    if ((rc = enqueue_transform(c, c->d_data32, c->d_data32, 4, inverse != 0, s, shift))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, d_data, n);
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, sc.d_data32, n, n);
+    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, 4, inverse != 0, s, shift))) return rc;
+    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, d_data, n);
     return (int)hipGetLastError();
 }
 
@@ -974,9 +1063,10 @@ int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint6
 // fft_ext of a short coefficient vector (src/math/domain.rs:134-151 pads each coordinate column to the domain size): the
 // four coordinate columns as one batch-of-4 low-degree extension, padding implied
 static int enqueue_lde_ext(toyni_ntt_ctx* c, size_t compact, uint32_t shift, hipStream_t s) {
-    // in: c->d_lde32 = [4][compact] coordinate columns; out: c->d_data32 = [4][n]
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
+    // in: sc.d_lde32 = [4][compact] coordinate columns; out: sc.d_data32 = [4][n]
     const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
-    return enqueue_lde(c, c->d_lde32, c->d_data32, 4, log_blowup, shift, s);
+    return enqueue_lde(c, sc.d_lde32, sc.d_data32, 4, log_blowup, shift, s);
 }
 
 int toyni_lde_ext_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, unsigned log_blowup, uint32_t shift, void* stream) {
@@ -985,13 +1075,14 @@ int toyni_lde_ext_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     const size_t n = c->n, n_in = n >> log_blowup;
     int rc;
-    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, 4 * n_in, sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n_in)), dim3(256), 0, s, d_coeffs, c->d_lde32, n_in, n_in);
+    if ((rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, 4 * n_in, sizeof(uint32_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n_in)), dim3(256), 0, s, d_coeffs, sc.d_lde32, n_in, n_in);
     if ((rc = enqueue_lde_ext(c, n_in, shift, s))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, d_out, n);
+    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, d_out, n);
     return (int)hipGetLastError();
 }
 
@@ -1006,18 +1097,20 @@ int toyni_lde_ext_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeff
     size_t compact = 1;
     while (compact < ncoeffs) compact <<= 1;
     hipStream_t s = c->stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
-    if ((rc = grow((void**)&c->d_stage64, &c->stage64_elems, 4 * n, sizeof(uint64_t)))) return rc;
-    if ((rc = grow((void**)&c->d_data32, &c->data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void**)&c->d_lde32, &c->lde32_words, 4 * compact, sizeof(uint32_t)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_stage64, h_coeffs, 4 * ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(c->d_lde32, 0, 4 * compact * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(ncoeffs)), dim3(256), 0, s, c->d_stage64, c->d_lde32, ncoeffs, compact);
+    if ((rc = grow(c, s, (void**)&sc.d_stage64, &sc.stage64_elems, 4 * n, sizeof(uint64_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
+    if ((rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, 4 * compact, sizeof(uint32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(sc.d_stage64, h_coeffs, 4 * ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(sc.d_lde32, 0, 4 * compact * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(ncoeffs)), dim3(256), 0, s, sc.d_stage64, sc.d_lde32, ncoeffs, compact);
     if ((rc = enqueue_lde_ext(c, compact, (uint32_t)shift, s))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, c->d_data32, c->d_stage64, n);
+    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, c->d_stage64, 4 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_out, sc.d_stage64, 4 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    reclaim_after_sync(c, s);
     return TOYNI_OK;
 }
 
@@ -1214,31 +1307,38 @@ int toyni_fri_fold_ext_host(uint64_t* h_out, const uint64_t* h_evals, size_t len
     if (len % 2) return TOYNI_E_ODD_LENGTH;  // src/math/fri.rs:8
     if (len == 0) return TOYNI_OK;
     const size_t half = len / 2;
-    std::vector<uint32_t> e32(4 * len), x32(half), o32(4 * half);
-    for (size_t i = 0; i < 4 * len; ++i) e32[i] = (uint32_t)(h_evals[i] % BB_P);
-    for (size_t i = 0; i < half; ++i) {
-        x32[i] = (uint32_t)(h_xs[i] % BB_P);
-        if (x32[i] == 0) return TOYNI_E_ZERO_INVERSE;
-    }
     uint32_t b32[4];
     for (int k = 0; k < 4; ++k) b32[k] = (uint32_t)(beta[k] % BB_P);
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
-    uint32_t *d_e = nullptr, *d_x = nullptr, *d_o = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_e); (void)hipFree(d_x); (void)hipFree(d_o); };
-#define FOLD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
-    FOLD_TRY(hipMalloc((void**)&d_e, e32.size() * sizeof(uint32_t)));
-    FOLD_TRY(hipMalloc((void**)&d_x, half * sizeof(uint32_t)));
-    FOLD_TRY(hipMalloc((void**)&d_o, o32.size() * sizeof(uint32_t)));
-    FOLD_TRY(hipMemcpy(d_e, e32.data(), e32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FOLD_TRY(hipMemcpy(d_x, x32.data(), half * sizeof(uint32_t), hipMemcpyHostToDevice));
-    int rc = toyni_fri_fold_ext_xs_device(d_e, d_x, d_o, len, b32, nullptr);
-    if (rc) { cleanup(); return rc; }
-    FOLD_TRY(hipMemcpy(o32.data(), d_o, o32.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-#undef FOLD_TRY
-    cleanup();
-    for (size_t i = 0; i < o32.size(); ++i) h_out[i] = o32[i];
-    return TOYNI_OK;
+    HostStage* st = nullptr;
+    int dev = 0, rc;
+    if ((rc = host_stage_acquire(&st, &dev))) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    hipStream_t s = st->stream;
+    // slots: 0 = evals u64 [4 len] (later the folded Ext values u32 [4 half]), 1 = xs u64 [half] , 2 = evals u32, 3 = xs u32, 4 = out u64 [4 half]
+    if ((rc = host_stage_reserve(st, 0, 4 * len * sizeof(uint64_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 1, half * sizeof(uint64_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 2, 4 * len * sizeof(uint32_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 3, half * sizeof(uint32_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 4, 4 * half * sizeof(uint64_t)))) return rc;
+    uint64_t* d_e64 = (uint64_t*)st->buf[0];
+    uint64_t* d_x64 = (uint64_t*)st->buf[1];
+    uint32_t* d_e32 = (uint32_t*)st->buf[2];
+    uint32_t* d_x32 = (uint32_t*)st->buf[3];
+    uint32_t* d_o32 = (uint32_t*)st->buf[0];
+    uint64_t* d_o64 = (uint64_t*)st->buf[4];
+    HIPCHK(hipMemsetAsync(st->d_flag, 0, sizeof(uint32_t), s));
+    HIPCHK(hipMemcpyAsync(d_e64, h_evals, 4 * len * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x64, h_xs, half * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(4 * len)), dim3(256), 0, s, (const uint64_t*)d_e64, d_e32, 4 * len);
+    hipLaunchKernelGGL(narrow_nonzero_kernel, dim3(grid_for(half)), dim3(256), 0, s, (const uint64_t*)d_x64, d_x32, half, st->d_flag);
+    if ((rc = toyni_fri_fold_ext_xs_device(d_e32, d_x32, d_o32, len, b32, s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(4 * half)), dim3(256), 0, s, (const uint32_t*)d_o32, d_o64, 4 * half);
+    HIPCHK(hipGetLastError());
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, st->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_out, d_o64, 4 * half * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return flag ? TOYNI_E_ZERO_INVERSE : TOYNI_OK;  // src/babybear.rs:112 (the reference panics before returning anything)
 }
 
 int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, const uint64_t* h_xs, uint64_t beta) {
@@ -1246,30 +1346,34 @@ int toyni_fri_fold_host(uint64_t* h_out, const uint64_t* h_evals, size_t len, co
     if (len % 2) return TOYNI_E_ODD_LENGTH;  // src/math/fri.rs:28
     if (len == 0) return TOYNI_OK;
     const size_t half = len / 2;
-    std::vector<uint32_t> e32(len), x32(half);
-    for (size_t i = 0; i < len; ++i) e32[i] = (uint32_t)(h_evals[i] % BB_P);
-    for (size_t i = 0; i < half; ++i) {
-        x32[i] = (uint32_t)(h_xs[i] % BB_P);
-        if (x32[i] == 0) return TOYNI_E_ZERO_INVERSE;  // src/babybear.rs:112
-    }
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
-    uint32_t *d_e = nullptr, *d_x = nullptr, *d_o = nullptr;
-    int rc = TOYNI_OK;
-    auto cleanup = [&]() { (void)hipFree(d_e); (void)hipFree(d_x); (void)hipFree(d_o); };
-#define FOLD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
-    FOLD_TRY(hipMalloc((void**)&d_e, len * sizeof(uint32_t)));
-    FOLD_TRY(hipMalloc((void**)&d_x, half * sizeof(uint32_t)));
-    FOLD_TRY(hipMalloc((void**)&d_o, half * sizeof(uint32_t)));
-    FOLD_TRY(hipMemcpy(d_e, e32.data(), len * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FOLD_TRY(hipMemcpy(d_x, x32.data(), half * sizeof(uint32_t), hipMemcpyHostToDevice));
-    rc = toyni_fri_fold_xs_device(d_e, d_x, d_o, len, (uint32_t)(beta % BB_P), nullptr);
-    if (rc) { cleanup(); return rc; }
-    FOLD_TRY(hipMemcpy(x32.data(), d_o, half * sizeof(uint32_t), hipMemcpyDeviceToHost));
-#undef FOLD_TRY
-    cleanup();
-    for (size_t i = 0; i < half; ++i) h_out[i] = x32[i];
-    return TOYNI_OK;
+    HostStage* st = nullptr;
+    int dev = 0, rc;
+    if ((rc = host_stage_acquire(&st, &dev))) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    hipStream_t s = st->stream;
+    // slots: 0 = evals u64 [len] (later the folded layer u32 [half]), 1 = xs u64 [half] (later the output u64 [half]), 2 = evals u32, 3 = xs u32
+    if ((rc = host_stage_reserve(st, 0, len * sizeof(uint64_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 1, half * sizeof(uint64_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 2, len * sizeof(uint32_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 3, half * sizeof(uint32_t)))) return rc;
+    uint64_t* d_e64 = (uint64_t*)st->buf[0];
+    uint64_t* d_x64 = (uint64_t*)st->buf[1];
+    uint32_t* d_e32 = (uint32_t*)st->buf[2];
+    uint32_t* d_x32 = (uint32_t*)st->buf[3];
+    uint32_t* d_o32 = (uint32_t*)st->buf[0];
+    HIPCHK(hipMemsetAsync(st->d_flag, 0, sizeof(uint32_t), s));
+    HIPCHK(hipMemcpyAsync(d_e64, h_evals, len * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_x64, h_xs, half * sizeof(uint64_t), hipMemcpyHostToDevice, s));  // only xs[0 .. len/2) is read
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(len)), dim3(256), 0, s, (const uint64_t*)d_e64, d_e32, len);
+    hipLaunchKernelGGL(narrow_nonzero_kernel, dim3(grid_for(half)), dim3(256), 0, s, (const uint64_t*)d_x64, d_x32, half, st->d_flag);
+    if ((rc = toyni_fri_fold_xs_device(d_e32, d_x32, d_o32, len, (uint32_t)(beta % BB_P), s))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(half)), dim3(256), 0, s, (const uint32_t*)d_o32, d_x64, half);
+    HIPCHK(hipGetLastError());
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, st->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_out, d_x64, half * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return flag ? TOYNI_E_ZERO_INVERSE : TOYNI_OK;  // src/babybear.rs:112
 }
 
 // ---- Merkle commitment ----
@@ -1301,27 +1405,23 @@ int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts,
 int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, size_t n, uint8_t* h_levels) {
     if (!h_values || !h_levels) return TOYNI_E_NULL;
     if (n == 0) return TOYNI_OK;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
-    std::vector<uint32_t> v32(n);
-    for (size_t i = 0; i < n; ++i) v32[i] = (uint32_t)(h_values[i] % BB_P);
+    HostStage* st = nullptr;
+    int dev = 0, rc;
+    if ((rc = host_stage_acquire(&st, &dev))) return rc;
+    std::lock_guard<std::mutex> lk(st->mu);
+    hipStream_t s = st->stream;
     const size_t total = toyni_merkle_total_digests(n);
-    uint32_t* d_v = nullptr;
-    uint8_t *d_s = nullptr, *d_l = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_v); (void)hipFree(d_s); (void)hipFree(d_l); };
-#define MK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return (int)_e; } } while (0)
-    MK_TRY(hipMalloc((void**)&d_v, n * sizeof(uint32_t)));
-    MK_TRY(hipMalloc((void**)&d_l, total * 32));
-    MK_TRY(hipMemcpy(d_v, v32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (h_salts) {
-        MK_TRY(hipMalloc((void**)&d_s, n * 16));
-        MK_TRY(hipMemcpy(d_s, h_salts, n * 16, hipMemcpyHostToDevice));
-    }
-    int rc = toyni_merkle_commit_device(d_v, d_s, n, d_l, nullptr);
-    if (rc) { cleanup(); return rc; }
-    MK_TRY(hipMemcpy(h_levels, d_l, total * 32, hipMemcpyDeviceToHost));
-#undef MK_TRY
-    cleanup();
+    // slots: 0 = values u64, 1 = salts, 2 = values u32, 4 = all levels
+    if ((rc = host_stage_reserve(st, 0, n * sizeof(uint64_t)))) return rc;
+    if (h_salts && (rc = host_stage_reserve(st, 1, n * 16))) return rc;
+    if ((rc = host_stage_reserve(st, 2, n * sizeof(uint32_t)))) return rc;
+    if ((rc = host_stage_reserve(st, 4, total * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(st->buf[0], h_values, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (h_salts) HIPCHK(hipMemcpyAsync(st->buf[1], h_salts, n * 16, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n)), dim3(256), 0, s, (const uint64_t*)st->buf[0], (uint32_t*)st->buf[2], n);
+    if ((rc = toyni_merkle_commit_device((const uint32_t*)st->buf[2], h_salts ? (const uint8_t*)st->buf[1] : nullptr, n, (uint8_t*)st->buf[4], s))) return rc;
+    HIPCHK(hipMemcpyAsync(h_levels, st->buf[4], total * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return TOYNI_OK;
 }
 
@@ -1346,8 +1446,25 @@ int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, 
 }
 
 int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
-    (void)c;
-    return (int)hipStreamSynchronize((hipStream_t)stream);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        DeviceGuard guard(c->device);
+        reclaim_after_sync(c, (hipStream_t)stream);
+    }
+    return TOYNI_OK;
+}
+
+int toyni_ntt_ctx_trim(toyni_ntt_ctx* c) {
+    if (!c) return TOYNI_E_NULL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
+    c->scratch.clear();
+    for (auto& r : c->retired) (void)hipFree(r.ptr);
+    c->retired.clear();
+    return TOYNI_OK;
 }
 
 int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream) {
@@ -1356,9 +1473,10 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     if (c->plan.log_n == 0) return TOYNI_OK;
     if (c->plan.npasses > 1) {
-        int rc = grow((void**)&c->d_work, &c->work_words, batch * (size_t)c->n, sizeof(uint32_t));
+        int rc = grow(c, s, (void**)&sc.d_work, &sc.work_words, batch * (size_t)c->n, sizeof(uint32_t));
         if (rc) return rc;
     }
     const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
@@ -1367,7 +1485,7 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
     HIPCHK(hipEventCreate(&e1));
     int pass_index = 0;
     hipError_t err = hipSuccess;
-    bool ok = for_each_pass(c->plan, tables, inverse != 0, d_data, c->d_work, d_data, batch,
+    bool ok = for_each_pass(c->plan, tables, inverse != 0, d_data, sc.d_work, d_data, batch,
                             [&](auto pass, auto, const PassArgs& a, uint64_t nblocks) {
                                 using P = decltype(pass);
                                 if (err != hipSuccess) return;
@@ -1442,3 +1560,6 @@ int cuda_copy_from_device(uint64_t* h_dest, const uint64_t* d_src, size_t count)
 const char* cuda_get_error_string(int error) { return toyni_error_string(error); }
 
 }  // extern "C"
+
+// multi-GPU forms for a single-process host: cached per-device contexts, batch sharding, one transform over G devices
+#include "multi_gpu.hpp"

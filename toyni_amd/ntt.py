@@ -79,6 +79,30 @@ def ntt_host_multi_gpu(values: np.ndarray, n: int, devices, inverse: bool = Fals
     check(lib.toyni_ntt_host_multi_gpu(devs, len(devices), n, v.ctypes.data, v.size // n, int(inverse)), "multi-GPU host NTT failed")
 
 
+EXCHANGE_PEER_COPY, EXCHANGE_RCCL = 0, 1
+
+
+def ntt_slab_multi_gpu_host(values: np.ndarray, devices, inverse: bool = False, exchange: int = EXCHANGE_PEER_COPY) -> None:
+    """ONE transform of values.size u64 elements (natural order, in place) over len(devices) GPUs from this process: slab pass ->
+    one exchange (peer copies over xGMI, or RCCL grouped send/recv) -> relayout -> row transforms (toyni_ntt_slab_multi_gpu_host).
+    A device may be listed more than once with the peer-copy exchange (lanes on one device)."""
+    v = _as_u64(values)
+    n = _checked_len(v)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    check(lib.toyni_ntt_slab_multi_gpu_host(devs, len(devices), n, v.ctypes.data, int(inverse), exchange), "multi-GPU slab NTT failed")
+
+
+def ntt_slab_multi_gpu_device(n: int, devices, d_slabs, d_rows, inverse: bool = False, exchange: int = EXCHANGE_PEER_COPY) -> None:
+    """Device-resident form: d_slabs[g] / d_rows[g] are packed-u32 device pointers (ints) on devices[g] in the layouts of
+    include/toyni_hip.h 2b; forward overwrites the slabs and fills the rows, inverse the other way round.  Blocking."""
+    g = len(devices)
+    assert len(d_slabs) == g and len(d_rows) == g
+    devs = (ctypes.c_int * g)(*devices)
+    slabs = (c_void_p * g)(*d_slabs)
+    rows = (c_void_p * g)(*d_rows)
+    check(lib.toyni_ntt_slab_multi_gpu_device(devs, g, n, slabs, rows, int(inverse), exchange), "multi-GPU slab NTT failed")
+
+
 class NttContext:
     """Persistent per-n context: twiddles + reusable device buffers (NttCtx, cuda/ntt_kernel.cu:202-209)."""
 
@@ -167,6 +191,10 @@ class NttContext:
             out[name] = [ms[3 * d + p] / cnt[3 * d + p] if cnt[3 * d + p] else None for p in range(self.passes)]
             out["launches"][name] = [int(cnt[3 * d + p]) for p in range(self.passes)]
         return out
+
+    def trim(self) -> None:
+        """Device-wide synchronisation, then every intermediate buffer of the context is freed."""
+        check(lib.toyni_ntt_ctx_trim(self.handle), "trim failed")
 
     def synchronize(self, stream: int = 0) -> None:
         check(lib.toyni_stream_synchronize(self.handle, stream or None), "stream synchronize failed")
