@@ -38,6 +38,18 @@ using namespace toyni;
 static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
+// one tile of a pass, phase by phase: every thread runs phase k before any thread runs phase k + 1 (the pass' barriers)
+template <class P, int LZ = 0>
+static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
+    for (uint32_t tid = 0; tid < P::T; ++tid) P::template phase1<LZ>(a, b, tid, lds);
+    if constexpr (P::STEPS >= 2) {
+        for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds);
+    }
+    if constexpr (P::STEPS >= 3) {
+        for (uint32_t tid = 0; tid < P::T; ++tid) P::phase3(a, b, tid, lds);
+    }
+}
+
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
@@ -78,12 +90,12 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         using P = decltype(pass);
         constexpr int LZ = decltype(lzc)::value;
         std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);  // exact size: an out-of-range LDS word is an ASan error
+        std::vector<char> seen(nblocks, 0);
         for (uint64_t v = 0; v < nblocks; ++v) {
             const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);  // the persistent loop's virtual index -> tile
-            for (uint32_t tid = 0; tid < P::T; ++tid) P::template phase1<LZ>(a, b, tid, lds.data());
-            if constexpr (P::TWO_STEP) {
-                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
-            }
+            CHECK(b < nblocks && !seen[b], "tile_order is not a bijection: v=%llu -> %u of %llu", (unsigned long long)v, b, (unsigned long long)nblocks);
+            if (b < nblocks) seen[b] = 1;
+            emu_tile<P, LZ>(a, b, lds.data());
         }
     }, cs, lde_log);
     CHECK(ok, "no pass instantiation for log_n=%d", plan.log_n);
@@ -276,13 +288,7 @@ static void emu_slab_pass(const NttPlan& plan, bool inverse, uint32_t* slab, uin
     bool ok = slab_pass(plan, blob.data(), inverse, slab, cols, col_base, ones, [&](auto pass, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
         std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);
-        for (uint64_t v = 0; v < nblocks; ++v) {
-            const uint32_t b = P::tile_order((uint32_t)v, (uint32_t)nblocks);
-            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase1(a, b, tid, lds.data());
-            if constexpr (P::TWO_STEP) {
-                for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds.data());
-            }
-        }
+        for (uint64_t v = 0; v < nblocks; ++v) emu_tile<P>(a, P::tile_order((uint32_t)v, (uint32_t)nblocks), lds.data());
     });
     CHECK(ok, "slab pass rejected: log_n=%d cols=%llu", plan.log_n, (unsigned long long)cols);
 }

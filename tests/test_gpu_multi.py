@@ -27,7 +27,7 @@ def ta():
     return toyni_amd
 
 
-@pytest.mark.parametrize("log_n,lanes", [(11, 1), (12, 2), (13, 4), (16, 8), (20, 1), (20, 4), (21, 8), (22, 2), (24, 8)])
+@pytest.mark.parametrize("log_n,lanes", [(11, 1), (12, 2), (13, 2), (16, 8), (20, 1), (20, 4), (21, 8), (22, 2), (24, 8)])
 def test_slab_multi_gpu_host_natural_order(ta, log_n, lanes):
     n = 1 << log_n
     x = oracle.splitmix(n, 4100 + log_n + lanes)

@@ -114,6 +114,10 @@ struct Pass {
     static_assert(LE2 <= LE1 && LE1 <= 5 && LE1 >= 1, "step sizes");
     static constexpr int LM = LE1 + LE2;
     static constexpr int LE1_ = LE1;
+    static constexpr int STEPS = LE2 > 0 ? 2 : 1;
+    // log2 of the row distance between two consecutive registers of a thread on the way in (step 1) and of the sub-index
+    // distance between two consecutive stores on the way out (last step): what the host needs for the coset factor cs_g
+    static constexpr int IN_STEP_LOG = LE2, OUT_STEP_LOG = LE2 > 0 ? LE1 : 0;
     static constexpr bool NT = NT_;
     static constexpr uint32_t M = 1u << LM, E1 = 1u << LE1, E2 = 1u << LE2, C = 1u << LC;
     static constexpr uint32_t T = C * E2;          // threads per workgroup
@@ -515,6 +519,276 @@ struct Pass {
     static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
         const Tile t = tile_of(a, tile_id);
         step2(a, t, tid, lds, seeds_finish(a, seeds_issue(a, t, tid)), load_uniform(a));
+    }
+};
+
+// ---- three-step passes: the latency configuration (a single transform, or a handful) ----
+// A lone n = 2^20 transform is 32 tiles of the 32-wide streaming shape and 128 of the 8-wide one: at most half the chip
+// works, and every wave walks 32 elements through ~1 800 instructions on its own.  Pass3 cuts the same M-point
+// sub-transform into THREE register steps of LE1 + LE2 + LE3 stage bits with only E = 2^LE1 <= 16 elements per thread and
+// tiles of C = 4 columns / rows: 4x the workgroups (every CU gets one at n = 2^20) and half the serial work per wave.
+// The data of such launches is cache-resident, so the narrow (16-byte) row segments cost little -- streaming launches keep
+// the 32-wide two-step shapes above.
+//   position r = (a << (LE2+LE3)) | (b << LE3) | d      a: LE1 bits (step 1, registers), b: LE2 bits (step 2), d: LE3 bits (step 3)
+//   step 1: thread <-> (c, lo = (b, d)), registers over a   -- per-thread twiddles, LDS write
+//   step 2: group  <-> (c, a, d),        registers over b   -- per-thread twiddles, in place in LDS
+//   step 3: group  <-> (c, hm = (a, b)), registers over d   -- uniform twiddles (SGPRs), inter-pass twiddle / scaling, HBM store
+//   output sub-index of (a, b, d): k = rev(d) << (LE1+LE2) | rev(b) << LE1 | rev(a) = rev(d) << (LE1+LE2) | rev_{LE1+LE2}(hm)
+// LDS: KIND_COL word(c, r) = r C + c + (r >> LE3) PADC; KIND_ROW_T word(c, r) = c PITCH + r + (r >> LE3): every access of a
+// thread is one base register + a compile-time immediate; steps 1 and 2 are conflict-free, step 3 of the column kind too.
+template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false>
+struct Pass3 {
+    static_assert(KIND == KIND_COL || KIND == KIND_ROW_T, "passes of multi-pass plans");
+    static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 4, "step sizes");
+    static constexpr int STEPS = 3;
+    static constexpr int LM = LE1 + LE2 + LE3, LLO = LE2 + LE3, LHM = LE1 + LE2;
+    static constexpr int IN_STEP_LOG = LLO, OUT_STEP_LOG = LHM;
+    static constexpr bool NT = NT_;
+    static constexpr uint32_t M = 1u << LM, E = 1u << LE1, E2 = 1u << LE2, E3 = 1u << LE3, C = 1u << LC;
+    static constexpr uint32_t T = C << LLO;            // threads per workgroup = C * M / E
+    static constexpr uint32_t G2 = E / E2, G3 = E / E3;  // step-2 / step-3 groups per thread
+    static_assert(T >= 64 && T <= 1024, "workgroup size");
+    using Stg = Pass<KIND_ROW_N, 5, 5, 3>;              // the stage code is shared (static members, independent of the shape)
+
+    static constexpr uint32_t PADC = C < 32 ? C : 0;
+    static constexpr uint32_t PITCH = (M + (M >> LE3)) | 1u;
+    static constexpr uint32_t LDS_WORDS = KIND == KIND_COL ? M * C + (M >> LE3) * PADC : C * PITCH;
+    static constexpr uint32_t TW_WORDS = M - E3;        // stages LE3 .. LM-1 of the packed stage table, kept in LDS
+    static constexpr uint32_t MIN_WAVES = 4;
+    // LDS word distance between two consecutive registers of a thread in step 1 / 2 / 3
+    static constexpr uint32_t STRIDE1 = KIND == KIND_COL ? (C << LLO) + (PADC << LE2) : (1u << LLO) + (1u << LE2);
+    static constexpr uint32_t STRIDE2 = KIND == KIND_COL ? (C << LE3) + PADC : E3 + 1u;
+    static constexpr uint32_t STRIDE3 = KIND == KIND_COL ? C : 1u;
+    static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t r) {
+        return KIND == KIND_COL ? r * C + c + (r >> LE3) * PADC : c * PITCH + r + (r >> LE3);
+    }
+
+    struct Tile {
+        const uint32_t* in;
+        uint32_t* out;
+        uint32_t row_shift, col0, out0;
+    };
+    // XCD-aware order: G = 32 / C consecutive tiles share 128-byte lines; within every 8 G consecutive virtual indices they
+    // go to workgroups p, p + 8, ... (one XCD under round-robin dispatch).  A bijection; placement only ever affects speed.
+    static TOYNI_HD uint32_t tile_order(uint32_t v, uint32_t ntiles) {
+        constexpr uint32_t G = C < 32 ? 32u / C : 1u;
+        if (G == 1 || (ntiles & (8u * G - 1u)) != 0) return v;
+        const uint32_t s = v & (8u * G - 1u);
+        return (v & ~(8u * G - 1u)) | ((s & 7u) * G + (s >> 3));
+    }
+    static TOYNI_HD Tile tile_of(const PassArgs& a, uint32_t bid) {
+        Tile t;
+        t.col0 = 0;
+        t.out0 = 0;
+        t.row_shift = 0;
+        if (KIND == KIND_COL) {
+            const uint32_t tiles_log = a.log_S - LC;
+            const uint64_t prefix = (uint64_t)bid >> tiles_log;
+            t.col0 = (bid & ((1u << tiles_log) - 1)) << LC;
+            t.in = a.in + ((prefix << a.in_prefix_log) + t.col0);
+            t.out = a.out + ((prefix << (a.log_S + LM)) + t.col0);
+            t.col0 += a.col_base;
+        } else {
+            const uint32_t mid = bid & ((1u << a.log_mid) - 1);
+            const uint32_t k1_tiles_log = a.log_M1 - LC;
+            const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << LC;
+            const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
+            t.row_shift = a.log_n - a.log_M1;
+            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM));
+            t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
+            t.out0 = k1_0 + (mid << a.log_M1);
+        }
+        return t;
+    }
+    static TOYNI_HD uint32_t in_offset(const PassArgs& a, const Tile& t, uint32_t c, uint32_t r) {
+        return KIND == KIND_COL ? (r << a.log_S) + c : (c << t.row_shift) + r;
+    }
+    static TOYNI_HD uint32_t out_offset(const PassArgs& a, uint32_t c, uint32_t k) {
+        return KIND == KIND_COL ? (k << a.log_S) + c : c + (k << (a.log_n - LM));
+    }
+
+    // thread coordinates: lanes run over what is contiguous in HBM (columns / the row) in step 1 and over the LDS-contiguous
+    // direction in step 2; in step 3 over the tile's columns / rows (contiguous in the output)
+    static TOYNI_HD void coords1(uint32_t tid, uint32_t& c, uint32_t& lo) {
+        if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
+        else { lo = tid & ((1u << LLO) - 1u); c = tid >> LLO; }
+    }
+    static TOYNI_HD void coords2(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& aa, uint32_t& d) {
+        const uint32_t gamma = tid + g * T;
+        if (KIND == KIND_COL) { c = gamma & (C - 1); d = (gamma >> LC) & (E3 - 1); aa = gamma >> (LC + LE3); }
+        else { d = gamma & (E3 - 1); aa = (gamma >> LE3) & (E - 1); c = gamma >> (LE3 + LE1); }
+    }
+    static TOYNI_HD void coords3(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& hm) {
+        const uint32_t gamma = tid + g * T;
+        c = gamma & (C - 1);
+        hm = gamma >> LC;
+    }
+
+    static constexpr uint32_t NU = E3 / 2 ? E3 / 2 : 1;
+    struct Uniform { uint32_t w[NU]; };
+    static TOYNI_HD Uniform load_uniform(const PassArgs& a) {
+        Uniform u;
+#pragma unroll
+        for (uint32_t q = 0; q < NU; ++q) u.w[q] = TOYNI_UNIFORM(a.stage_tw[NU - 1u + q]);
+        return u;
+    }
+    // twiddle slice kept in LDS: words [E3 - 1, M - 1) of the packed stage table; `tw` below points at its first word
+    static TOYNI_HD const uint32_t* tw_global(const PassArgs& a) { return a.stage_tw + (E3 - 1u); }
+
+    // ---- step 1: HBM -> registers (E elements: r = lo + (i << LLO)), coset input scaling, LE1 stages, park in LDS ----
+    struct InSeedRaw { uint32_t lo, hi; };
+    static TOYNI_HD InSeedRaw in_seed_issue(const PassArgs& a, const Tile& t, uint32_t tid) {
+        InSeedRaw r{0u, 0u};
+        if (KIND == KIND_COL && a.cs_mode == 1u) {
+            uint32_t c, lo;
+            coords1(tid, c, lo);
+            const uint32_t j0 = (lo << a.log_S) + t.col0 + c;
+            r.lo = a.cs_lo[j0 & ((1u << a.cs_lowbits) - 1u)];
+            r.hi = a.cs_hi[j0 >> a.cs_lowbits];
+        }
+        return r;
+    }
+    template <int LZ = 0>
+    static TOYNI_HD void load_tile(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E]) {
+        static_assert(LZ == 0 || KIND == KIND_COL, "zero-padded input is a first (column) pass feature");
+        constexpr uint32_t NZ = E >> (LZ < LE1 ? LZ : LE1);
+        uint32_t c, lo;
+        coords1(tid, c, lo);
+        const bool live = LZ < LE1 || lo < a.nz_rows;
+        const uint32_t off0 = in_offset(a, t, c, lo) << 2;
+        const uint32_t step = (in_offset(a, t, 0u, 1u << LLO) - in_offset(a, t, 0u, 0u)) << 2;
+        const char* base = reinterpret_cast<const char*>(t.in);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i)
+            x[i] = (live && i < NZ) ? ld32<NT_>(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0) : 0u;
+    }
+    template <int LZ = 0>
+    static TOYNI_HD void step1(const PassArgs& a, const InSeedRaw& seed, uint32_t tid, uint32_t (&x)[E], uint32_t* lds, const uint32_t* tw) {
+        constexpr uint32_t NZ = E >> (LZ < LE1 ? LZ : LE1);
+        uint32_t c, lo;
+        coords1(tid, c, lo);
+        if (KIND == KIND_COL && a.cs_mode == 1u) {   // forward coset transform: x[j] *= s^j, a running product over the registers
+            uint32_t tw0 = mont_mul(seed.hi, seed.lo);
+#pragma unroll
+            for (uint32_t i = 0; i < NZ; ++i) {
+                x[i] = mont_mul(x[i], tw0);
+                if (i + 1 < NZ) { tw0 = mont_mul(tw0, a.cs_g); TOYNI_PIN(tw0); }
+            }
+        }
+        const uint32_t* tw1 = tw + ((1u << LLO) - E3);   // the table from stage LLO on
+        if constexpr (LZ == 0) Stg::template stages<LE1, LLO>(x, tw1, lo, nullptr);
+        else Stg::template stages_lz<LE1, LLO, LZ, LE1 - 1>(x, tw1, lo, nullptr);
+        const uint32_t base = lds_word(c, lo);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) lds[base + i * STRIDE1] = x[i];
+    }
+
+    // ---- step 2: the LE2 middle stage bits, in place in LDS ----
+    static TOYNI_HD void step2(uint32_t tid, uint32_t* lds, const uint32_t* tw) {
+#pragma unroll
+        for (uint32_t g = 0; g < G2; ++g) {
+            uint32_t c, aa, d;
+            coords2(tid, g, c, aa, d);
+            uint32_t x[E2];
+            const uint32_t base = lds_word(c, (aa << LLO) + d);
+#pragma unroll
+            for (uint32_t j = 0; j < E2; ++j) x[j] = lds[base + j * STRIDE2];
+            Stg::template stages<LE2, LE3>(x, tw, d, nullptr);
+#pragma unroll
+            for (uint32_t j = 0; j < E2; ++j) lds[base + j * STRIDE2] = x[j];
+        }
+    }
+
+    // ---- step 3: the LE3 low stage bits (uniform twiddles), inter-pass twiddle / coset output scaling, store ----
+    // the factor of output k = (b << LHM) | khi of a group is A * G^b (see Pass::group_twiddle_issue): two-level table lookups,
+    // issued ahead of the barriers
+    struct SeedsRaw { uint32_t a_lo[G3], a_hi[G3], g_lo, g_hi; };
+    struct Seeds { uint32_t a0[G3], g; };
+    static TOYNI_HD SeedsRaw seeds_issue(const PassArgs& a, const Tile& t, uint32_t tid) {
+        SeedsRaw s{};
+#pragma unroll
+        for (uint32_t g = 0; g < G3; ++g) {
+            uint32_t c, hm;
+            coords3(tid, g, c, hm);
+            const uint32_t khi = bitrev32(hm, LHM);
+            if (KIND == KIND_COL) {
+                const uint32_t jcol = t.col0 + c;
+                const uint32_t mask = (1u << a.tw_lowbits) - 1u;
+                const uint32_t ea = jcol * khi;
+                s.a_lo[g] = a.tw_lo[ea & mask];
+                s.a_hi[g] = a.tw_hi[ea >> a.tw_lowbits];
+                if (g == 0) {   // G = w_L^(j' << LHM) depends on the column only, and a thread's groups share it
+                    const uint32_t eg = jcol << LHM;
+                    s.g_lo = a.tw_lo[eg & mask];
+                    s.g_hi = a.tw_hi[eg >> a.tw_lowbits];
+                }
+            } else if (a.cs_mode == 2u) {
+                const uint32_t e0 = t.out0 + c + (khi << (a.log_n - LM));
+                s.a_lo[g] = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
+                s.a_hi[g] = a.cs_hi[e0 >> a.cs_lowbits];
+            }
+        }
+        return s;
+    }
+    static TOYNI_HD Seeds seeds_finish(const PassArgs& a, const SeedsRaw& r) {
+        Seeds s{};
+        if (KIND == KIND_COL) {
+            s.g = mont_mul(r.g_hi, r.g_lo);
+#pragma unroll
+            for (uint32_t g = 0; g < G3; ++g) {
+                s.a0[g] = mont_mul(r.a_hi[g], r.a_lo[g]);
+                if (a.scale) s.a0[g] = mont_mul(s.a0[g], a.scale);
+            }
+        } else if (a.cs_mode == 2u) {
+            s.g = a.cs_g;
+#pragma unroll
+            for (uint32_t g = 0; g < G3; ++g) s.a0[g] = mont_mul(r.a_hi[g], r.a_lo[g]);
+        }
+        return s;
+    }
+    static TOYNI_HD void step3(const PassArgs& a, const Tile& t, uint32_t tid, const uint32_t* lds, const Seeds& seeds, const Uniform& uni) {
+        const bool twiddled = KIND == KIND_COL || a.cs_mode == 2u;
+#pragma unroll
+        for (uint32_t g = 0; g < G3; ++g) {
+            uint32_t c, hm;
+            coords3(tid, g, c, hm);
+            uint32_t x[E3];
+            const uint32_t base = lds_word(c, hm << LE3);
+#pragma unroll
+            for (uint32_t j = 0; j < E3; ++j) x[j] = lds[base + j * STRIDE3];
+            Stg::template stages<LE3, 0>(x, nullptr, 0u, uni.w);
+            const uint32_t khi = bitrev32(hm, LHM);
+            const uint32_t off0 = out_offset(a, c, khi) << 2;
+            const uint32_t step = (out_offset(a, 0u, 1u << LHM) - out_offset(a, 0u, 0u)) << 2;
+            char* obase = reinterpret_cast<char*>(t.out);
+            uint32_t tw0 = seeds.a0[g];
+#pragma unroll
+            for (uint32_t b = 0; b < E3; ++b) {
+                uint32_t v = x[cx_bitrev(b, LE3)];
+                if (twiddled) {
+                    v = mont_mul(v, tw0);
+                    if (b + 1 < E3) { tw0 = mont_mul(tw0, seeds.g); TOYNI_PIN(tw0); }
+                }
+                st32<NT_>(reinterpret_cast<uint32_t*>(obase + (uint64_t)b * step), off0, v);
+            }
+        }
+    }
+
+    // whole-tile phases, one thread each (tests/emu runs phase k for every thread before phase k + 1: the pass' two barriers)
+    template <int LZ = 0>
+    static TOYNI_HD void phase1(const PassArgs& a, uint32_t tile_id, uint32_t tid, uint32_t* lds) {
+        const Tile t = tile_of(a, tile_id);
+        uint32_t x[E];
+        load_tile<LZ>(a, t, tid, x);
+        step1<LZ>(a, in_seed_issue(a, t, tid), tid, x, lds, tw_global(a));
+    }
+    static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, uint32_t* lds) {
+        (void)tile_id;
+        step2(tid, lds, tw_global(a));
+    }
+    static TOYNI_HD void phase3(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
+        const Tile t = tile_of(a, tile_id);
+        step3(a, t, tid, lds, seeds_finish(a, seeds_issue(a, t, tid)), load_uniform(a));
     }
 };
 

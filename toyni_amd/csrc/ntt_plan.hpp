@@ -139,8 +139,27 @@ inline bool build_plan(int log_n, NttPlan& plan) {
 // cover the chip the narrower variants (16 / 8 wide) are used -- the data is cache-resident at that size anyway.
 // `log_tiles32` = log2 of the number of 32-wide tiles the launch would have.
 // nt: the non-temporal variant of the same shape (streaming launches, see ld32 / st32).
+// Launches of at most 2^pass3_max_log_tiles32() 32-wide tiles (a single transform, or a handful: the data is cache-resident
+// and the chip is far from full) run the three-step shapes `Pass3` with 4-wide tiles instead: 8x the workgroups of the 32-wide
+// shape and half the serial work per wave.  -1 = never.  (A variable so that tests/emu can step both executors and the library
+// can take TOYNI_P3_TILES from the environment.)
+inline int& pass3_max_log_tiles32() {
+    static int v = 6;
+    return v;
+}
+
 template <class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
+    if (log_tiles32 <= pass3_max_log_tiles32()) {
+#define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false>{}); return true; }
+        TOYNI_PASS3_CASE(KIND_COL, 3, 3, 2)
+        TOYNI_PASS3_CASE(KIND_COL, 3, 3, 3)
+        TOYNI_PASS3_CASE(KIND_COL, 4, 3, 3)
+        TOYNI_PASS3_CASE(KIND_ROW_T, 3, 3, 2)
+        TOYNI_PASS3_CASE(KIND_ROW_T, 3, 3, 3)
+        TOYNI_PASS3_CASE(KIND_ROW_T, 4, 3, 3)
+#undef TOYNI_PASS3_CASE
+    }
 #define TOYNI_PASS_GO(K, A, B, LC_) do { if (nt) f(Pass<K, A, B, LC_, true>{}); else f(Pass<K, A, B, LC_, false>{}); } while (0)
 #define TOYNI_PASS_CASE(K, A, B, LC_) \
     if (kind == K && log_m == (A) + (B)) { TOYNI_PASS_GO(K, A, B, LC_); return true; }
@@ -195,6 +214,11 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
         default: return false;                                                               \
     }
 #define TOYNI_COMMA ,
+    if (log_tiles32 <= pass3_max_log_tiles32()) {
+        if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
+        if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+        if (log_m == 10) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+    }
     if (log_m == 6) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
     if (log_m == 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
     if (log_m == 8) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 5>) }
@@ -267,9 +291,9 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
                 a.cs_mode = inverse ? 2u : 1u;
                 // index distance between two consecutive registers of a thread
                 uint64_t dj;
-                if (!inverse) dj = pp.kind == KIND_COL ? ((uint64_t)P::E2 << pp.log_s) : (uint64_t)P::E2;
-                else dj = pp.kind == KIND_ROW_T ? ((uint64_t)1 << (P::TWO_STEP ? P::LE1_ : 0)) << (plan.log_n - P::LM)
-                                                : ((uint64_t)1 << (P::TWO_STEP ? P::LE1_ : 0));
+                if (!inverse) dj = pp.kind == KIND_COL ? (((uint64_t)1 << P::IN_STEP_LOG) << pp.log_s) : ((uint64_t)1 << P::IN_STEP_LOG);
+                else dj = pp.kind == KIND_ROW_T ? ((uint64_t)1 << P::OUT_STEP_LOG) << (plan.log_n - P::LM)
+                                                : ((uint64_t)1 << P::OUT_STEP_LOG);
                 a.cs_g = to_mont_host(bb_pow_host(cs.s, dj));
             }
             uint64_t nblocks;

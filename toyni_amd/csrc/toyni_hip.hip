@@ -99,6 +99,42 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
     }
 }
 
+// Three-step passes (Pass3, ntt_kernels.hpp): the latency configuration.  Persistent over its tiles without a software
+// prefetch: with 16 elements per thread the kernel is light on registers, and the launches it serves have at most a few
+// tiles per CU.  The step-3 twiddle lookups are issued with the tile's loads and stay in flight across both barriers.
+template <class P, int LZ = 0>
+__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const PassArgs a, const uint32_t ntiles) {
+    __shared__ uint32_t lds[P::LDS_WORDS + P::TW_WORDS];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v = blockIdx.x;
+    if (v >= ntiles) return;
+    uint32_t* lds_tw = lds + P::LDS_WORDS;
+    for (uint32_t j = tid; j < P::TW_WORDS; j += P::T) lds_tw[j] = P::tw_global(a)[j];
+    const typename P::Uniform uni = P::load_uniform(a);
+    __syncthreads();
+    while (true) {
+        const typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
+        uint32_t x[P::E];
+        P::template load_tile<LZ>(a, t, tid, x);
+        const typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
+        const typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
+        P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw);
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        P::step2(tid, lds, lds_tw);
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        P::step3(a, t, tid, lds, P::seeds_finish(a, raw), uni);
+        v += gridDim.x;
+        if (v >= ntiles) break;
+        TOYNI_SCHED_FENCE();
+        TOYNI_BARRIER();  // every wave has its step-3 LDS reads in registers before the tile is overwritten
+        TOYNI_SCHED_FENCE();
+    }
+}
+
 // Single-sweep transform for n = 2^11 .. 2^15 (LdsPass, ntt_kernels.hpp): one 1024-thread workgroup per CU keeps a tile of
 // 32 rows x 1024 words in LDS through all three phases; persistent over the tiles of the batch.  The next tile's loads
 // are issued as soon as phase A has parked the registers in LDS, ahead of this tile's stores (vmcnt retires in issue
@@ -605,7 +641,9 @@ int prefetch_depth() {
 
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
-    if constexpr (LZ > 0) {  // LDE first pass: one kernel each
+    if constexpr (P::STEPS == 3) {
+        hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    } else if constexpr (LZ > 0) {  // LDE first pass: one kernel each
         hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else {
         if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
@@ -619,7 +657,10 @@ template <class P>
 unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
     static const int per_cu = [] {  // once per instantiation (thread-safe initialisation)
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0) != hipSuccess || occ < 1) occ = 1;
+        hipError_t qe;
+        if constexpr (P::STEPS == 3) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3_kernel<P, 0>, (int)P::T, 0);
+        else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0);
+        if (qe != hipSuccess || occ < 1) occ = 1;
         if (const char* env = std::getenv("TOYNI_WG_PER_CU")) { int v = std::atoi(env); if (v > 0) occ = v; }
         return occ;
     }();
@@ -824,6 +865,7 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     c->device = device;
     if (!build_plan(ilog2(n), c->plan)) { delete c; return TOYNI_E_INVALID_SIZE; }
     if (const char* env = std::getenv("TOYNI_CHUNK_ELEMS")) c->chunk_elems = (size_t)std::strtoull(env, nullptr, 0);
+    if (const char* env = std::getenv("TOYNI_P3_TILES")) pass3_max_log_tiles32() = std::atoi(env);  // tuning knob (-1: never the three-step shapes)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
