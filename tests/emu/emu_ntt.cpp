@@ -39,8 +39,10 @@ static int failures = 0;
 #define CHECK(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
 
 // one tile of a pass, phase by phase: every thread runs phase k before any thread runs phase k + 1 (the pass' barriers)
+static unsigned long long tiles_by_steps[4] = {0, 0, 0, 0};
 template <class P, int LZ = 0>
 static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
+    ++tiles_by_steps[P::STEPS];
     for (uint32_t tid = 0; tid < P::T; ++tid) P::template phase1<LZ>(a, b, tid, lds);
     if constexpr (P::STEPS >= 2) {
         for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds);
@@ -381,6 +383,10 @@ int main(int argc, char** argv) {
     }
     for (int i = 2; i < argc; ++i) {                // extra sizes "LOG" or "LOGxBATCH" (2-pass 2^20, 3-pass 2^21.., wide tiles)
         const char* xb = std::strchr(argv[i], 'x');
+        if (argv[i][0] == 'p') {                    // "pN": launches of <= 2^N 32-wide tiles take the three-step shapes from here on (-1: never)
+            pass3_max_log_tiles32() = std::atoi(argv[i] + 1);
+            continue;
+        }
         if (argv[i][0] == 'l') {                    // "lLOGxZ": low-degree extension of 2^(LOG-Z) coefficients to 2^LOG points
             test_lde(std::atoi(argv[i] + 1), 2, xb ? std::atoi(xb + 1) : 5, 7);
             std::printf("lde %s failures=%d\n", argv[i], failures);
@@ -419,6 +425,7 @@ int main(int argc, char** argv) {
     test_fold_ext(2);
     test_fold_ext(64);
     test_fold_ext(1024);
+    std::printf("tiles stepped: one-step %llu, two-step %llu, three-step %llu\n", tiles_by_steps[1], tiles_by_steps[2], tiles_by_steps[3]);
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
     return failures ? 1 : 0;
 }

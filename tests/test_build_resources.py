@@ -24,7 +24,7 @@ def test_no_kernel_spills_and_occupancy_targets_hold():
     seen = 0
     for b in blocks:
         name = b.split(" ")[0]
-        if "ntt_pass_kernel" not in name and "ntt_lds_kernel" not in name:
+        if "ntt_pass_kernel" not in name and "ntt_lds_kernel" not in name and "ntt_pass3_kernel" not in name:
             continue
 
         def field(key):

@@ -12,12 +12,18 @@ def test_kernel_bodies_match_oracle_on_cpu():
     # batch 4, 32-wide at batch 16 -- the streaming configuration) and 2^21 (3-pass)
     # sLOGxG: one transform split over G emulated ranks (slab pass / relayout / row transforms, include/toyni_hip.h 2b):
     # 2^20 over 2 (1024-point first pass, 8-wide tiles) and 2^21 over 4 (3-pass plan); 2^13, 2^14 run by default
-    res = subprocess.run([exe, "14", "20", "20x4", "20x16", "21", "s20x2", "s21x4",
+    # pN: launches of at most 2^N 32-wide tiles run the three-step latency shapes (Pass3); the default (6) covers the single
+    # transforms above, "p-1" then repeats 2^16 / 2^18 / 2^20 (and their LDE / slab forms) on the two-step shapes alone
+    res = subprocess.run([exe, "14", "16", "18", "19", "20", "20x2", "20x4", "20x16", "21", "s20x2", "s21x4", "s18x4",
                           # lLOGxZ: low-degree extension with 2^Z-fold implied zero padding -- every remaining first-pass shape
                           # ((4,4) at 2^16, (5,4) at 2^18, (5,5) at 2^20) across zero fractions, incl. blow-ups > 32
-                          "l16x1", "l16x4", "l16x5", "l16x8", "l18x3", "l18x5", "l18x9", "l20x1", "l20x3", "l20x4", "l20x7", "l20x10", "l24x5"], capture_output=True, text=True, timeout=900)
+                          "l16x1", "l16x4", "l16x5", "l16x8", "l18x3", "l18x5", "l18x9", "l20x1", "l20x3", "l20x4", "l20x7", "l20x10", "l24x5",
+                          "p-1", "16", "18", "20", "s20x2", "l16x5", "l18x3", "l20x5", "l20x10"], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout
+    import re
+    m = re.search(r"tiles stepped: one-step (\d+), two-step (\d+), three-step (\d+)", res.stdout)
+    assert m and int(m.group(2)) > 0 and int(m.group(3)) > 0, "both the two-step and the three-step shapes must have run"
 
 
 def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
@@ -25,6 +31,7 @@ def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
     # the LDS array exactly LDS_WORDS): 2^0..2^11 with ragged batches (2^11 also through the single-sweep LDS kernel in all its
     # workgroup shapes), 2^13 / 2^15 (single-sweep, 32-row tiles), 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
     exe = entry.build_emu_sanitized()
-    res = subprocess.run([exe, "11", "13", "15", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6"], capture_output=True, text=True, timeout=900)
+    res = subprocess.run([exe, "11", "13", "15", "16", "18", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6", "p-1", "16", "20", "l20x6"],
+                         capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "ALL OK" in res.stdout
