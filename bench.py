@@ -189,6 +189,37 @@ def probe_ranks(args):
         dist.destroy_process_group()
 
 
+def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
+    """HBM traffic and VALU instruction counts cannot be collected inside this process (rocprofv3 --pmc runs the command from
+    outside): they are the COMMITTED rocprofv3 measurements of the same command (tools/collect_profiles.sh -> profiles/
+    rNN_traffic*.json, rNN_counters*.json), looked up by (log_n, batch); newest round first.  (None, None, None) if this
+    workload has no committed measurement."""
+    import glob
+    traffic = traffic_src = valu = None
+    want = "Pass<1" if dom_is_last_pass else "Pass<0"   # kernel symbols carry the pass KIND: 0 = strided column pass, 1 = closing row pass
+    for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        tj = json.load(open(tfile))
+        if tj.get("log_n") != log_n or tj.get("batch_per_gpu") != batch:
+            continue
+        kernels = [(k, v) for k, v in tj["kernels"].items() if want in k]
+        if not kernels:
+            continue
+        k, v = max(kernels, key=lambda kv: kv[1].get("rocprof_avg_ns") or 0)
+        traffic, traffic_src = v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tfile)} ({k.split('(')[0]})"
+        cfile = tfile.replace("_traffic", "_counters")
+        if os.path.exists(cfile):
+            cj = json.load(open(cfile))
+            insts = [c.get("SQ_INSTS_VALU") for kk, c in cj.items() if "ntt_pass" in kk and kk in tj["kernels"]]
+            if insts and all(insts):
+                lane_ops = sum(insts) * 64.0 / (n * batch)
+                ach = lane_ops * n * batch / t_fwd_s / 1e12
+                valu = {"lane_ops_per_element_per_transform": lane_ops, "achieved_Tops": ach, "peak_Tops": 39.3, "frac": ach / 39.3,
+                        "note": "forward transform; peak = the 4-cycle instruction class (mul/mad/min/add3) at 2.4 GHz; add/sub/xor issue "
+                                "faster (~60 T lane-ops/s, profiles/r02_microbench.txt); sustained clock under this load is ~2.0-2.1 GHz"}
+        break
+    return traffic, traffic_src, valu
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -331,32 +362,7 @@ def main():
         # batch, so its share is 8 * n * batch / npass.
         alg_bytes = 8.0 * n * batch / npass
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            if tj.get("log_n") == args.log_n and tj.get("batch_per_gpu") == batch:
-                # PMC numbers cannot be collected inside this process; this is the committed rocprofv3 measurement of the
-                # same command (tools/collect_profiles.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch of the dominant kernel
-                want = "Pass<0" if dom == 0 else "Pass<1"
-                for k, v in tj["kernels"].items():
-                    if want in k:
-                        traffic, traffic_src = v["hbm_bytes_per_launch"], f"profiles/r01_traffic.json ({k.split('(')[0]})"
-        # The binding resource is VALU issue, not HBM: report it next to the required HBM object.
-        # instructions/element from the committed rocprofv3 SQ_INSTS_VALU of the same command; peak = 256 CUs x 4 SIMDs x
-        # 64 lanes / 4 cycles x 2.4 GHz = 39.3 T lane-ops/s (measured with `--microbench`: integer multiplies issue at the add rate)
-        valu = None
-        cfile = os.path.join(ROOT, "profiles", "r01_counters.json")
-        if os.path.exists(cfile) and traffic is not None:
-            cj = json.load(open(cfile))
-            per_launch = {("Pass<0" if "Pass<0" in k else "Pass<1"): v.get("SQ_INSTS_VALU") for k, v in cj.items() if "ntt_pass_kernel" in k and "5, 5, 5" in k}
-            if all(per_launch.get(x) for x in ("Pass<0", "Pass<1")):
-                lane_ops_per_elem = (per_launch["Pass<0"] + per_launch["Pass<1"]) * 64.0 / (n * batch)
-                t_fwd = sum(fwd_ms) * 1e-3
-                ach = lane_ops_per_elem * n * batch / t_fwd / 1e12
-                valu = {"lane_ops_per_element_per_transform": lane_ops_per_elem, "achieved_Tops": ach, "peak_Tops": 39.3,
-                        "frac": ach / 39.3, "note": "forward transform; sustained clock under this load is ~2.0 GHz (GRBM_GUI_ACTIVE), "
-                                                    "i.e. ~0.84 of the issue rate at that clock"}
+        traffic, traffic_src, valu = committed_counters(args.log_n, batch, npass > 1 and dom == npass - 1, n, sum(fwd_ms) * 1e-3)
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,
@@ -455,6 +461,27 @@ def main():
         t24 = time_dev(fb24, 5)
         extras["batched_n2^24"] = {"batch": b24, "ms_per_fwd_inv": t24 * 1e3, "elements_per_s": 2 * b24 * n24 / t24,
                                    "passes_per_transform": c24.passes, "note": "same step as `value` at n = 2^24"}
+        # the same roofline object for this size: per-pass launch durations from HIP events around the launches of 5 more steps
+        c24.timing(True)
+        for _ in range(5):
+            fb24()
+        torch.cuda.synchronize()
+        r24 = c24.read_timing()
+        c24.timing(False)
+        f24, i24 = r24["forward"], r24["inverse"]
+        np24 = c24.passes
+        d24 = max(range(np24), key=lambda p: f24[p] + i24[p])
+        d24_ms = 0.5 * (f24[d24] + i24[d24])
+        alg24 = 8.0 * n24 * b24 / np24
+        tr24, tr24_src, _ = committed_counters(24, b24, np24 > 1 and d24 == np24 - 1, n24, sum(f24) * 1e-3)
+        extras["batched_n2^24"]["roofline"] = {
+            "bound": "hbm", "achieved": alg24 / (d24_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg24 / (d24_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tr24, "traffic_source": tr24_src,
+            "kernel": f"ntt_pass_kernel, pass {d24} of {np24}", "kernel_ms": d24_ms, "algorithmic_bytes_per_launch": alg24,
+            "all_pass_ms": {"forward": f24, "inverse": i24},
+            "kernel_stream_GBps": 8.0 * n24 * b24 / (d24_ms * 1e-3) / 1e9,
+            "transform_algorithmic_GBps": 8.0 * n24 * b24 / (sum(f24) * 1e-3) / 1e9,
+        }
         c24.destroy()
 
         # ---- low-degree extension of a batch of columns (src/fibonacci.rs:101-103, blowup 32, coset shift 7): zero padding
@@ -483,71 +510,102 @@ def main():
         del coeffs, ext, ref
         c_lde.destroy()
 
-        # ---- prover-shaped sequence (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident: the NTT /
-        #      fold work of one proof: interpolate (INTT 2^16), coset LDE (zero-pad + coset FFT 2^21), the two coset INTTs of
-        #      src/fibonacci.rs:145,151, and the 17 FRI folds 2^21 -> 2^4 (src/fibonacci.rs:220-245).  Merkle/transcript and
-        #      the pointwise constraint evaluation are outside this path.
+        # ---- the transforms of one proof (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident, single
+        #      transforms back to back: interpolate (INTT 2^16), coset LDE 2^16 -> 2^21, the two coset INTTs of src/fibonacci.rs:145,151
         lt, ll = 16, 21
         c_t, c_l = toyni_amd.NttContext(1 << lt, device=dev.index), toyni_amd.NttContext(1 << ll, device=dev.index)
         trace = torch.randint(0, P, (1 << lt,), dtype=torch.int32, device=dev)
         lde = torch.zeros(1 << ll, dtype=torch.int32, device=dev)
         q1 = torch.randint(0, P, (1 << ll,), dtype=torch.int32, device=dev)
         q2 = torch.randint(0, P, (1 << ll,), dtype=torch.int32, device=dev)
-        layers = torch.empty(1 << ll, dtype=torch.int32, device=dev)
-        betas = np.random.default_rng(5).integers(0, P, 17, dtype=np.uint32)
+        t_intt16 = time_dev(lambda: c_t.run_device(trace.data_ptr(), trace.data_ptr(), 1, True, stream=stream), 50)
+        t_lde21 = time_dev(lambda: c_l.lde_device(trace.data_ptr(), lde.data_ptr(), 1, 5, 7, stream=stream), 50)
+        t_cntt21 = time_dev(lambda: c_l.run_device(q1.data_ptr(), q1.data_ptr(), 1, False, stream=stream, shift=7), 50)
+        t_cintt21 = time_dev(lambda: c_l.run_device(q2.data_ptr(), q2.data_ptr(), 1, True, stream=stream, shift=7), 50)
+        extras["prover_transforms_trace2^16_lde2^21"] = {
+            "intt_2^16_us": t_intt16 * 1e6, "lde_2^16_to_2^21_us": t_lde21 * 1e6, "coset_ntt_2^21_us": t_cntt21 * 1e6,
+            "coset_intt_2^21_us": t_cintt21 * 1e6, "note": "single transforms, kernel-only (latency configuration: three-step 4-wide tiles where the launch is small)"}
 
-        def prove_shape():
-            c_t.run_device(trace.data_ptr(), lde.data_ptr(), 1, True, stream=stream)          # coefficients into lde[0 : 2^16]
-            lde[(1 << lt):].zero_()
-            c_l.run_device(lde.data_ptr(), lde.data_ptr(), 1, False, stream=stream, shift=7)   # coset LDE
-            c_l.run_device(q1.data_ptr(), q1.data_ptr(), 1, True, stream=stream, shift=7)      # ifft #1
-            c_l.run_device(q2.data_ptr(), q2.data_ptr(), 1, True, stream=stream, shift=7)      # ifft #2
-            toyni_amd.fri_fold_layers_device(c_l, lde.data_ptr(), layers.data_ptr(), betas, 7, stream=stream)
+        # ---- the FRI phase as the PROTOCOL orders it (src/fibonacci.rs:222-245): beta_{k+1} is squeezed from a transcript that has
+        #      absorbed round k's Merkle root, so every round is: fold + commit on the device -> 32-byte root to the host -> SHA-256
+        #      transcript -> next beta.  17 rounds 2^21 -> 2^4.  `fused`: toyni_fri_fold_commit_device (leaf hashes inside the fold's
+        #      sweep); `separate`: toyni_fri_fold_device + toyni_merkle_commit_device.
+        import hashlib
+        from toyni_amd._lib import lib as _tlib
+        n_l = 1 << ll
+        salts_all = torch.randint(0, 255, (n_l, 16), dtype=torch.uint8, device=dev)
+        lay = [torch.empty(n_l >> k, dtype=torch.int32, device=dev) for k in range(18)]
+        lay[0].copy_(q1)
+        lvls = [torch.empty((_tlib.toyni_merkle_total_digests(n_l >> k), 32), dtype=torch.uint8, device=dev) for k in range(18)]
 
-        t_p = time_dev(prove_shape, 20)
-        extras["prover_shape_trace2^16_lde2^21"] = {
-            "us": t_p * 1e6, "note": "INTT 2^16 + coset FFT 2^21 + 2 coset INTT 2^21 + 17 folds, device-resident, 22 launches",
-        }
-        # the same sequence captured once into a hipGraph (the launch path allocates nothing after warm-up) and replayed
-        try:
-            side = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(side):
-                gstream = side.cuda_stream
+        def fri_phase(fused):
+            state = b"toyni-stark-v1"
+            x0 = 7
+            for k in range(17):
+                state = hashlib.sha256(state).digest()                       # squeeze_challenge, src/transcript.rs
+                beta = int.from_bytes(state[:8], "little") % P
+                m = n_l >> k
+                salted = (m // 2) != 16
+                sp = salts_all.data_ptr() if salted else 0
+                if fused:
+                    toyni_amd.prover.fri_fold_commit_device(c_l, lay[k].data_ptr(), lay[k + 1].data_ptr(), m, beta, x0, sp, lvls[k + 1].data_ptr(), stream=stream)
+                else:
+                    toyni_amd.fri_fold_device(c_l, lay[k].data_ptr(), lay[k + 1].data_ptr(), m, beta, x0, stream=stream)
+                    toyni_amd.merkle_commit_device(lay[k + 1].data_ptr(), sp, m // 2, lvls[k + 1].data_ptr(), stream=stream)
+                x0 = x0 * x0 % P
+                state += lvls[k + 1][-1].cpu().numpy().tobytes()             # absorb_commitment: the root crosses PCIe, the stream drains
+            return state
 
-                def prove_shape_on(st):
-                    c_t.run_device(trace.data_ptr(), lde.data_ptr(), 1, True, stream=st)
-                    c_l.run_device(lde.data_ptr(), lde.data_ptr(), 1, False, stream=st, shift=7)
-                    c_l.run_device(q1.data_ptr(), q1.data_ptr(), 1, True, stream=st, shift=7)
-                    c_l.run_device(q2.data_ptr(), q2.data_ptr(), 1, True, stream=st, shift=7)
-                    toyni_amd.fri_fold_layers_device(c_l, lde.data_ptr(), layers.data_ptr(), betas, 7, stream=st)
+        assert fri_phase(True) == fri_phase(False), "fused and separate FRI rounds disagree"
 
-                prove_shape_on(gstream)
-                side.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    prove_shape_on(torch.cuda.current_stream().cuda_stream)
-            t_g = time_dev(graph.replay, 20)
-            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_replay_us"] = t_g * 1e6
-        except Exception as exc:  # capture support is a property of the runtime, not of the kernels
-            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_replay_us"] = None
-            extras["prover_shape_trace2^16_lde2^21"]["hipgraph_error"] = str(exc)[:200]
+        def wall(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0w = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0w) / reps
+
+        extras["fri_phase_protocol_order_2^21"] = {
+            "fused_fold_commit_ms": wall(lambda: fri_phase(True), 5) * 1e3, "separate_fold_then_commit_ms": wall(lambda: fri_phase(False), 5) * 1e3,
+            "rounds": 17, "note": "wall time incl. the per-round root read-back and host transcript (beta_{k+1} depends on root_k)"}
+        del lay, lvls, salts_all
 
         # ---- BASELINE configs[2]: the whole prover-shaped harness (tests/harness/fib_prover.py) at trace_len 2^16, blowup 32:
-        #      GPU LDE + coset INTTs + 17 folds + 20 Merkle trees + transcript + 44 query openings; host work (OOD Horner,
-        #      hashing the transcript, path extraction) included.  The proof is checked by the verifier restatement in tests.
+        #      every heavy step is a device call of this library (LDE, constraint/quotient, coset INTTs, OOD evaluations, DEEP, 17
+        #      fold+commit rounds, 20 Merkle trees, ~1 700 openings); host work = transcript hashing.  The proof is checked by the
+        #      verifier restatement in tests; timed here in its serialized form (openings as the records the device wrote).
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from harness import fib_prover
             col = fib_prover.fibonacci_trace(1 << 16)
-            fib_prover.generate_proof(col, seed=11)            # warm (contexts, tables)
-            torch.cuda.synchronize()
-            t0p = time.perf_counter()
-            fib_prover.generate_proof(col, seed=12)
-            torch.cuda.synchronize()
-            extras["fib_prove_trace2^16_blowup32"] = {"ms": (time.perf_counter() - t0p) * 1e3,
-                                                      "note": "harness wall time, one proof, warm; the reference prover is infeasible at this size (O(n^3) interpolation, SURVEY F5)"}
+            fib_prover.generate_proof(col, seed=11, raw=True)            # warm (contexts, tables)
+            times = []
+            for sd in (12, 13, 14):
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                fib_prover.generate_proof(col, seed=sd, raw=True)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0p) * 1e3)
+            phases = {}
+            fib_prover.generate_proof(col, seed=15, raw=True, timing=phases)
+            extras["fib_prove_trace2^16_blowup32"] = {"ms": sorted(times)[1], "ms_all": times, "phase_ms_with_syncs": phases,
+                                                      "note": "harness wall time, one proof, warm, median of 3; the reference prover is infeasible at this size (O(n^3) interpolation, SURVEY F5)"}
         except Exception as exc:
-            extras["fib_prove_trace2^16_blowup32"] = {"ms": None, "error": str(exc)[:200]}
+            extras["fib_prove_trace2^16_blowup32"] = {"ms": None, "error": str(exc)[:300]}
+
+        # the reference-shaped fold call fri_fold(evals, xs, beta) on host slices (src/math/fri.rs:27-48), PCIe inclusive
+        hm = 1 << 20
+        he = np.random.default_rng(7).integers(0, P, hm, dtype=np.uint64)
+        hx = np.random.default_rng(8).integers(1, P, hm, dtype=np.uint64)
+        toyni_amd.fri_fold(he, hx, 12345)
+        t0h = time.perf_counter()
+        for _ in range(5):
+            toyni_amd.fri_fold(he, hx, 12345)
+        th = (time.perf_counter() - t0h) / 5
+        extras["fri_fold_host_m2^20"] = {"ms": th * 1e3, "GBps_algorithmic": 6.0 * hm / th / 1e9,
+                                         "note": "toyni_fri_fold_host: u64 evals + xs up, u64 layer down, explicit points (one Fermat chain per 4), pageable memory"}
 
         # Merkle commitment of one lde-size layer (the prover builds 3 of these plus 17 shrinking FRI layers): SURVEY 8(f) rank 2
         from toyni_amd._lib import lib as _tlib

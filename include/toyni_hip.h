@@ -215,6 +215,39 @@ int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts,
 int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, size_t n, uint8_t* h_levels);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3c. One FRI round, and the pointwise steps of the Fibonacci prover on the LDE coset (oracle:
+ *     src/fibonacci.rs:133-150,186-198,222-245, src/math/polynomial.rs:134-144, src/merkle.rs:50-80).  All asynchronous on
+ *     `stream`; packed u32 device data; ctx = a context of size N = the LDE size (its domain table supplies x_i = shift w_N^i).
+ * ---------------------------------------------------------------------------------------------- */
+/* One round of the fold loop (src/fibonacci.rs:222-245): d_out = fri_fold(d_evals) on the points x0 w_m^i with challenge
+ * beta, AND the Merkle tree of the folded layer in d_levels (layout of toyni_merkle_commit_device over m/2 leaves; the leaf
+ * hashes are computed in the fold's own sweep; d_salts = (m/2) x 16 bytes, or NULL for the unsalted final layer).  The next
+ * beta depends on this tree's root (the last 32 bytes of d_levels), so a round is as far as the protocol lets the fusion go. */
+int toyni_fri_fold_commit_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0,
+                                 const uint8_t* d_salts, uint8_t* d_levels, void* stream);
+/* Constraint and quotient evaluations (src/fibonacci.rs:133-150): with n = N >> log_blowup, g = w_n, T(g x_i) = trace[(i + B) mod N]:
+ *   c_i = (T(g^2 x_i) - (T(g x_i) + T(x_i))) (x_i - g^(n-1)) (x_i - g^(n-2)),   q_i = c_i / (x_i^n - 1).
+ * d_c_evals may be NULL.  TOYNI_E_ZERO_INVERSE if Z_H vanishes on the coset (shift^n a B-th root of unity). */
+int toyni_fib_quotient_device(toyni_ntt_ctx* ctx, const uint32_t* d_trace_lde, uint32_t* d_c_evals, uint32_t* d_q_evals, unsigned log_blowup,
+                              uint32_t shift, void* stream);
+/* DEEP layer (src/fibonacci.rs:186-198): d_i = ((q_i - q_z) + (T(g^2 x_i) - t_ggz) + (T(g x_i) - t_gz) + (T(x_i) - t_z)) / (x_i - z);
+ * ood = {t_z, t_gz, t_ggz, q_z}.  z must lie outside the coset (derive_z_from_transcript, :379-399, guarantees it); a point
+ * with x_i = z yields 0 for that point alone (the reference panics: "Cannot invert zero"). */
+int toyni_fib_deep_device(toyni_ntt_ctx* ctx, const uint32_t* d_trace_lde, const uint32_t* d_q_evals, uint32_t* d_out, unsigned log_blowup,
+                          uint32_t shift, uint32_t z, const uint32_t ood[4], void* stream);
+/* Polynomial::evaluate (src/math/polynomial.rs:134-144) of ncoeffs device-resident coefficients at 1..4 points (host values):
+ * d_out[p] = sum_i c_i points[p]^i.  The OOD evaluations t_z, t_gz, t_ggz share one read of the coefficients. */
+int toyni_poly_eval_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, size_t ncoeffs, const uint32_t* points, unsigned npoints,
+                           uint32_t* d_out, void* stream);
+/* Openings (open_merkle, src/fibonacci.rs:366-375, over MerkleTree::get_proof, src/merkle.rs:50-80) of nidx leaves of a tree built
+ * by toyni_merkle_commit_device / toyni_fri_fold_commit_device, gathered on the device into nidx records of
+ * toyni_merkle_open_record_bytes(n) bytes each:  depth x 32 path bytes | 16 salt bytes (zero if d_salts is NULL) | the value as
+ * 8 LE bytes | depth position bytes (1 = the sibling is the LEFT input), padded to a multiple of 8.  d_out 8-byte aligned. */
+size_t toyni_merkle_open_record_bytes(size_t n);
+int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* d_values, const uint8_t* d_salts, const uint32_t* d_indices,
+                             size_t nidx, uint8_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 4. Plumbing
  * ---------------------------------------------------------------------------------------------- */
 int toyni_malloc(void** d_ptr, size_t bytes);

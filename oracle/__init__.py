@@ -63,6 +63,10 @@ for _name, _res, _args in [
     ("orc_merkle_total_digests", _sz, [_sz]),
     ("orc_merkle_levels", None, [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     ("orc_merkle_commit_values", None, [ctypes.c_void_p, _p64, ctypes.c_void_p, _sz]),
+    ("orc_poly_eval", _u64, [_p64, _sz, _u64]),
+    ("orc_fib_quotient", ctypes.c_int, [ctypes.c_void_p, _p64, _p64, _sz, _sz, _u64]),
+    ("orc_fib_deep", ctypes.c_int, [_p64, _p64, _p64, _sz, _sz, _u64, _u64, _u64, _u64, _u64, _u64]),
+    ("orc_merkle_get_proof", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz]),
     ("orc_fill_pattern_7i3", None, [_p64, _sz]),
     ("orc_fill_splitmix", None, [_p64, _sz, _u64]),
 ]:
@@ -249,3 +253,42 @@ def merkle_commit_values(values, salts=None) -> list:
         sp = s.ctypes.data
     _lib.orc_merkle_commit_values(flat.ctypes.data, _ptr(v), sp, n)
     return _split_levels(flat, n)
+
+
+# ---- pointwise prover steps (src/fibonacci.rs:133-150,186-198; src/math/polynomial.rs:134-144; src/merkle.rs:50-80) ----
+def poly_eval(coeffs, x) -> int:
+    c = _arr(coeffs)
+    return int(_lib.orc_poly_eval(_ptr(c), c.size, int(x)))
+
+
+def fib_quotient(trace_lde, n, shift):
+    """(c_evals, q_evals) on the coset shift * <w_N>, N = len(trace_lde)."""
+    t = _arr(trace_lde)
+    c = np.empty(t.size, dtype=np.uint64)
+    q = np.empty(t.size, dtype=np.uint64)
+    rc = _lib.orc_fib_quotient(c.ctypes.data, _ptr(q), _ptr(t), t.size, n, shift)
+    assert rc != -3, "Cannot invert zero"
+    assert rc == 0
+    return c, q
+
+
+def fib_deep(trace_lde, q_evals, n, shift, z, t_z, t_gz, t_ggz, q_z) -> np.ndarray:
+    t, q = _arr(trace_lde), _arr(q_evals)
+    out = np.empty(t.size, dtype=np.uint64)
+    rc = _lib.orc_fib_deep(_ptr(out), _ptr(t), _ptr(q), t.size, n, shift, z, t_z, t_gz, t_ggz, q_z)
+    assert rc != -3, "Cannot invert zero"
+    assert rc == 0
+    return out
+
+
+def merkle_get_proof(levels, index):
+    """MerkleTree::get_proof on the levels of merkle_levels / merkle_commit_values: (path digests, position flags) or None."""
+    n = len(levels[0])
+    flat = np.ascontiguousarray(np.concatenate(levels), dtype=np.uint8)
+    depth = len(levels) - 1
+    path = np.zeros((max(depth, 1), 32), dtype=np.uint8)
+    pos = np.zeros(max(depth, 1), dtype=np.uint8)
+    d = _lib.orc_merkle_get_proof(path.ctypes.data, pos.ctypes.data, flat.ctypes.data, n, index)
+    if d < 0:
+        return None
+    return [path[l].tobytes() for l in range(d)], [bool(pos[l]) for l in range(d)]

@@ -422,3 +422,87 @@ void orc_merkle_commit_values(uint8_t *levels, const uint64_t *values, const uin
     }
     orc_merkle_build_upper(levels, n);
 }
+
+/* ---- pointwise steps of the Fibonacci prover on the LDE coset ----------------------------
+ * Restated on EVALUATIONS: with lde_domain = shift * <w_N>, g = w_n = w_N^B (B = N / n), the reference's
+ * trace_poly.evaluate(g * x_i) (src/fibonacci.rs:137-141) is the LDE value at position (i + B) mod N -- the same
+ * identity the reference itself uses for its query openings (:261-266).  Everything else is the reference's formula
+ * with its own operation order (one division per term, Fermat inverses). */
+
+/* src/math/polynomial.rs:134-144  Polynomial::evaluate (Horner) */
+uint64_t orc_poly_eval(const uint64_t *coeffs, size_t n, uint64_t x) {
+    if (n == 0) return 0;
+    uint64_t result = coeffs[n - 1] % BB_P;
+    for (size_t k = n - 1; k-- > 0;) result = orc_bb_add(orc_bb_mul(result, x), coeffs[k] % BB_P);
+    return result;
+}
+
+/* src/fibonacci.rs:133-150: c_evals and q_evals over the coset; fibonacci_constraint :313-315,
+ * boundary_constraint_1/2 :318-324, z_poly = x^n - 1 (vanishing_poly_coeffs).  c_out may be NULL. */
+int orc_fib_quotient(uint64_t *c_out, uint64_t *q_out, const uint64_t *trace_lde, size_t N, size_t n, uint64_t shift) {
+    if (N == 0 || (N & (N - 1)) || n < 2 || (n & (n - 1)) || n > N) return -1;
+    const size_t B = N / n;
+    uint64_t *xs = (uint64_t *)malloc(N * sizeof(uint64_t));
+    if (!xs) return -2;
+    orc_domain_elements(xs, N, shift);
+    const uint64_t g = orc_bb_root_of_unity(orc_log2(n));
+    const uint64_t b1 = orc_bb_pow(g, (uint64_t)(n - 1)), b2 = orc_bb_pow(g, (uint64_t)(n - 2));
+    for (size_t i = 0; i < N; ++i) {
+        const uint64_t x = xs[i];
+        const uint64_t t0 = trace_lde[i], t1 = trace_lde[(i + B) % N], t2 = trace_lde[(i + 2 * B) % N];
+        const uint64_t fib = orc_bb_sub(t2, orc_bb_add(t1, t0));
+        const uint64_t c = orc_bb_mul(orc_bb_mul(fib, orc_bb_sub(x, b1)), orc_bb_sub(x, b2));
+        const uint64_t zh = orc_bb_sub(orc_bb_pow(x, (uint64_t)n), 1);
+        if (zh == 0) { free(xs); return -3; } /* "Cannot invert zero" */
+        if (c_out) c_out[i] = c;
+        q_out[i] = orc_bb_div(c, zh);
+    }
+    free(xs);
+    return 0;
+}
+
+/* src/fibonacci.rs:186-198: the DEEP layer, four quotients summed in the reference's order */
+int orc_fib_deep(uint64_t *out, const uint64_t *trace_lde, const uint64_t *q_evals, size_t N, size_t n, uint64_t shift,
+                 uint64_t z, uint64_t t_z, uint64_t t_gz, uint64_t t_ggz, uint64_t q_z) {
+    if (N == 0 || (N & (N - 1)) || n == 0 || n > N) return -1;
+    const size_t B = N / n;
+    uint64_t *xs = (uint64_t *)malloc(N * sizeof(uint64_t));
+    if (!xs) return -2;
+    orc_domain_elements(xs, N, shift);
+    for (size_t i = 0; i < N; ++i) {
+        const uint64_t d = orc_bb_sub(xs[i], z);
+        if (d == 0) { free(xs); return -3; }
+        const uint64_t t0 = trace_lde[i], t1 = trace_lde[(i + B) % N], t2 = trace_lde[(i + 2 * B) % N];
+        uint64_t acc = orc_bb_div(orc_bb_sub(q_evals[i], q_z), d);
+        acc = orc_bb_add(acc, orc_bb_div(orc_bb_sub(t2, t_ggz), d));
+        acc = orc_bb_add(acc, orc_bb_div(orc_bb_sub(t1, t_gz), d));
+        acc = orc_bb_add(acc, orc_bb_div(orc_bb_sub(t0, t_z), d));
+        out[i] = acc;
+    }
+    free(xs);
+    return 0;
+}
+
+/* src/merkle.rs:50-80 MerkleTree::get_proof on the flat level array of orc_merkle_levels: writes depth sibling digests
+ * to `path` and depth flags to `position` (1 = "is_right" in the reference's naming: the sibling is hashed on the left,
+ * :87-99); returns depth, or -1 when index >= n. */
+int orc_merkle_get_proof(uint8_t *path, uint8_t *position, const uint8_t *levels, size_t n, size_t index) {
+    if (index >= n) return -1;
+    size_t off = 0, m = n, cur = index;
+    int depth = 0;
+    while (m > 1) {
+        const size_t sib = (cur % 2 == 0) ? cur + 1 : cur - 1;
+        if (sib >= m) {
+            memcpy(path + 32 * (size_t)depth, levels + 32 * (off + cur), 32);
+            position[depth] = 1;
+        } else {
+            memcpy(path + 32 * (size_t)depth, levels + 32 * (off + sib), 32);
+            position[depth] = (uint8_t)(cur % 2 == 1);
+        }
+        off += m;
+        m = (m + 1) / 2;
+        cur /= 2;
+        ++depth;
+    }
+    return depth;
+}

@@ -24,6 +24,7 @@ fn main() {
     println!("cargo:rerun-if-changed=hip/bb_field.hpp");
     println!("cargo:rerun-if-changed=hip/merkle_kernels.hpp");
     println!("cargo:rerun-if-changed=hip/multi_gpu.hpp");
+    println!("cargo:rerun-if-changed=hip/prover_kernels.hpp");
     println!("cargo:rerun-if-changed=hip/toyni_hip.h");
     println!("cargo::rustc-check-cfg=cfg(has_hip)");
     if env::var_os("CARGO_FEATURE_HIP").is_none() {

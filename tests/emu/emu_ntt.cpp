@@ -13,6 +13,7 @@
 
 #include "ntt_plan.hpp"
 #include "merkle_kernels.hpp"
+#include "prover_kernels.hpp"
 
 extern "C" {
 uint64_t orc_bb_mul(uint64_t, uint64_t);
@@ -31,6 +32,11 @@ int orc_domain_fft(uint64_t*, size_t, const uint64_t*, size_t, uint64_t);
 void orc_merkle_commit_values(uint8_t*, const uint64_t*, const uint8_t*, size_t);
 size_t orc_merkle_total_digests(size_t);
 int orc_domain_ifft(uint64_t*, size_t, uint64_t);
+uint64_t orc_poly_eval(const uint64_t*, size_t, uint64_t);
+int orc_fib_quotient(uint64_t*, uint64_t*, const uint64_t*, size_t, size_t, uint64_t);
+int orc_fib_deep(uint64_t*, const uint64_t*, const uint64_t*, size_t, size_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+int orc_merkle_get_proof(uint8_t*, uint8_t*, const uint8_t*, size_t, size_t);
+uint64_t orc_bb_root_of_unity(uint32_t);
 }
 
 using namespace toyni;
@@ -353,6 +359,124 @@ static void test_slab(int log_n, uint64_t G) {
     }
 }
 
+// Pointwise prover steps (prover_kernels.hpp) against the oracle's restatement of src/fibonacci.rs:133-150,186-198
+static DomainArgs emu_domain(const NttPlan& plan, int log_m, uint32_t shift) {
+    DomainArgs d{};
+    d.lo = plan.fwd.data() + plan.dom_lo_off;
+    d.hi = plan.fwd.data() + plan.dom_hi_off;
+    d.lowbits = plan.dom_lowbits;
+    d.log_step = (uint32_t)(plan.log_n - log_m);
+    d.shiftR = to_mont_host(shift);
+    return d;
+}
+static void test_prover_steps(int log_N, int log_blowup, uint32_t shift) {
+    NttPlan plan;
+    CHECK(build_plan(log_N, plan), "plan");
+    const size_t N = (size_t)1 << log_N, n = N >> log_blowup, B = (size_t)1 << log_blowup;
+    std::vector<uint64_t> lde(N), cw(N), qw(N), dw(N);
+    orc_fill_splitmix(lde.data(), N, 0xF1B0 + log_N);
+    CHECK(orc_fib_quotient(cw.data(), qw.data(), lde.data(), N, n, shift) == 0, "oracle quotient");
+    std::vector<uint32_t> t32(N);
+    for (size_t i = 0; i < N; ++i) t32[i] = (uint32_t)lde[i];
+    QuotientArgs a{};
+    a.trace = t32.data();
+    a.dom = emu_domain(plan, log_N, shift);
+    a.log_N = (uint32_t)log_N;
+    a.log_blowup = (uint32_t)log_blowup;
+    const uint32_t g = (uint32_t)orc_bb_root_of_unity((uint32_t)(log_N - log_blowup));
+    a.b1R = to_mont_host(bb_pow_host(g, n - 1));
+    a.b2R = to_mont_host(bb_pow_host(g, n - 2));
+    a.shift_nR = to_mont_host(bb_pow_host(shift, n));
+    a.wBR = to_mont_host(bb_pow_host((uint32_t)orc_bb_root_of_unity((uint32_t)log_N), n));
+    size_t bad = 0;
+    std::vector<uint32_t> q32(N);
+    for (size_t i = 0; i < N; ++i) {
+        uint32_t c, q;
+        quotient_one(a, i, t32[i], t32[(i + B) % N], t32[(i + 2 * B) % N], quotient_zh_inv(a, (uint32_t)(i & (B - 1))), c, q);
+        q32[i] = q;
+        bad += c != (uint32_t)cw[i] || q != (uint32_t)qw[i];
+    }
+    CHECK(bad == 0, "quotient log_N=%d blowup=%d: %zu mismatches", log_N, log_blowup, bad);
+    const uint64_t z = 7654321, tz = 11, tgz = 22, tggz = 33, qz = 44;
+    CHECK(orc_fib_deep(dw.data(), lde.data(), qw.data(), N, n, shift, z, tz, tgz, tggz, qz) == 0, "oracle deep");
+    DeepArgs d{};
+    d.trace = t32.data();
+    d.quot = q32.data();
+    d.dom = a.dom;
+    d.log_N = (uint32_t)log_N;
+    d.log_blowup = (uint32_t)log_blowup;
+    d.wNR = to_mont_host((uint32_t)orc_bb_root_of_unity((uint32_t)log_N));
+    d.zR = to_mont_host((uint32_t)z);
+    d.t_z = tz; d.t_gz = tgz; d.t_ggz = tggz; d.q_z = qz;
+    bad = 0;
+    for (size_t i0 = 0; i0 + 8 <= N; i0 += 8) {
+        uint32_t t0[8], t1[8], t2[8], qv[8], out[8];
+        for (int j = 0; j < 8; ++j) { t0[j] = t32[i0 + j]; t1[j] = t32[(i0 + j + B) % N]; t2[j] = t32[(i0 + j + 2 * B) % N]; qv[j] = q32[i0 + j]; }
+        deep_group<8>(d, i0, t0, t1, t2, qv, out);
+        for (int j = 0; j < 8; ++j) bad += out[j] != (uint32_t)dw[i0 + j];
+    }
+    CHECK(bad == 0, "deep log_N=%d blowup=%d: %zu mismatches", log_N, log_blowup, bad);
+    // a point with x_i = z: that point alone yields 0, its seven neighbours are unaffected
+    {
+        std::vector<uint64_t> xs(N);
+        orc_domain_elements(xs.data(), N, shift);
+        d.zR = to_mont_host((uint32_t)xs[3]);
+        uint32_t t0[8], t1[8], t2[8], qv[8], out[8];
+        for (int j = 0; j < 8; ++j) { t0[j] = t32[j]; t1[j] = t32[(j + B) % N]; t2[j] = t32[(j + 2 * B) % N]; qv[j] = q32[j]; }
+        deep_group<8>(d, 0, t0, t1, t2, qv, out);
+        CHECK(out[3] == 0u, "deep zero point");
+        for (int j = 0; j < 8; ++j) {
+            if (j == 3) continue;
+            const uint64_t num = orc_bb_add(orc_bb_add(orc_bb_sub(qv[j], qz), orc_bb_sub(t2[j], tggz)), orc_bb_add(orc_bb_sub(t1[j], tgz), orc_bb_sub(t0[j], tz)));
+            CHECK(out[j] == (uint32_t)orc_bb_mul(num, orc_bb_inverse(orc_bb_sub(xs[j], xs[3]))), "deep neighbour of a zero point j=%d", j);
+        }
+    }
+}
+static void test_poly_eval(size_t ncoeffs, uint32_t z) {
+    std::vector<uint64_t> c64(ncoeffs);
+    orc_fill_splitmix(c64.data(), ncoeffs, 0x9017 + ncoeffs);
+    const uint64_t want = orc_poly_eval(c64.data(), ncoeffs, z);
+    PolyEvalArgs a{};
+    a.npoints = 1;
+    a.zR[0] = to_mont_host(z);
+    a.z16R[0] = to_mont_host(bb_pow_host(z, POLY_PER_THREAD));
+    a.zchunkR[0] = to_mont_host(bb_pow_host(z, POLY_CHUNK));
+    const size_t nblocks = (ncoeffs + POLY_CHUNK - 1) / POLY_CHUNK;
+    uint32_t total = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+        uint32_t part = 0;
+        for (uint32_t t = 0; t < POLY_THREADS; ++t) {
+            uint32_t c[POLY_PER_THREAD];
+            for (uint32_t j = 0; j < POLY_PER_THREAD; ++j) {
+                const size_t i = b * POLY_CHUNK + (size_t)t * POLY_PER_THREAD + j;
+                c[j] = i < ncoeffs ? (uint32_t)c64[i] : 0u;
+            }
+            part = bb_add(part, poly_thread_term(a, 0, c, t));
+        }
+        total = bb_add(total, mont_mul(part, mont_pow(a.zchunkR[0], b)));
+    }
+    CHECK(total == (uint32_t)want, "poly eval ncoeffs=%zu z=%u: got %u want %u", ncoeffs, z, total, (uint32_t)want);
+}
+static void test_merkle_open(size_t n) {
+    std::vector<uint64_t> vals(n);
+    orc_fill_splitmix(vals.data(), n, 0x0BE7 + n);
+    const size_t total = orc_merkle_total_digests(n);
+    std::vector<uint8_t> levels(32 * total), path(32 * 64), pos(64);
+    orc_merkle_commit_values(levels.data(), vals.data(), nullptr, n);
+    const uint32_t depth = merkle_depth(n);
+    for (size_t index = 0; index < n; ++index) {
+        const int d = orc_merkle_get_proof(path.data(), pos.data(), levels.data(), n, index);
+        CHECK(d == (int)depth, "depth n=%zu", n);
+        for (uint32_t l = 0; l < depth; ++l) {
+            bool is_left;
+            const uint64_t row = merkle_sibling_row(n, index, l, is_left);
+            CHECK(row < total && std::memcmp(levels.data() + 32 * row, path.data() + 32 * l, 32) == 0 && is_left == (pos[l] != 0),
+                  "merkle open n=%zu index=%zu level=%u", n, index, l);
+        }
+    }
+    CHECK(merkle_open_record_bytes(n) % 8 == 0, "record size");
+}
+
 int main(int argc, char** argv) {
     int max_log = argc > 1 ? std::atoi(argv[1]) : 16;
     test_field();
@@ -422,6 +546,11 @@ int main(int argc, char** argv) {
     test_fold(1, 0, 7);
     test_fold(6, 2, 1);
     for (size_t n : {1, 2, 3, 4, 5, 8, 100, 1024}) { test_merkle(n, false); test_merkle(n, true); }
+    test_prover_steps(6, 2, 7);
+    test_prover_steps(9, 5, 7);
+    test_prover_steps(8, 3, 1234567);
+    for (size_t nc : {1, 15, 16, 17, 4095, 4096, 4097, 10000}) { test_poly_eval(nc, 987654321u); test_poly_eval(nc, 0u); test_poly_eval(nc, 1u); }
+    for (size_t n : {1, 2, 3, 5, 8, 13, 100}) test_merkle_open(n);
     test_fold_ext(2);
     test_fold_ext(64);
     test_fold_ext(1024);

@@ -10,8 +10,12 @@ reference's own Lagrange interpolation (O(n^3)) and Horner LDE (O(N d)) are infe
   the two `ifft` calls   -> coset INTTs of size 32 n      (src/fibonacci.rs:145,151)
   FRI fold loop          -> structured-point fold kernel  (src/fibonacci.rs:220-245)
   Merkle commitments     -> GPU SHA-256 trees, levels stay on the device; only roots and the 44 query paths cross PCIe
-  pointwise constraint / quotient / DEEP arithmetic -> torch int64 elementwise ops on the device (plumbing: products of
-                            two residues stay below 2^62).  These are SURVEY 8(f)3 "next" and have no kernels of their own.
+  constraint / quotient  -> toyni_fib_quotient_device          (src/fibonacci.rs:133-150, one kernel)
+  OOD evaluations        -> toyni_poly_eval_device             (t_z, t_gz, t_ggz share one read of the coefficients)
+  DEEP layer             -> toyni_fib_deep_device              (src/fibonacci.rs:186-198, one inversion per 8 points)
+  FRI round              -> toyni_fri_fold_commit_device       (fold + leaf hashes in one sweep, then the node levels)
+  query openings         -> toyni_merkle_open_device           (all ~1 700 paths gathered on the device, ONE copy to the host)
+The only torch arithmetic left is the masking of 140 coefficients.
 
 Field arithmetic is exact, so every value equals what the reference's formulas define on the same randomness; the proof is
 checked by tests/harness/fib_verifier.py, a CPU restatement of src/verifier.rs.
@@ -29,26 +33,6 @@ NUM_QUERIES = 44          # src/fibonacci.rs:11
 BLOWUP = 32               # src/fibonacci.rs:14
 COSET_SHIFT = 7           # src/fibonacci.rs:16
 MASK_DEGREE = 3 * NUM_QUERIES + 8   # src/fibonacci.rs:19
-
-
-# ---- field helpers on int64 tensors (device plumbing) ----
-def mulmod(a, b):
-    return (a * b) % P
-
-
-def powmod_t(a, e: int):
-    r = torch.ones_like(a)
-    base = a.clone()
-    while e:
-        if e & 1:
-            r = mulmod(r, base)
-        base = mulmod(base, base)
-        e >>= 1
-    return r
-
-
-def invmod_t(a):
-    return powmod_t(a, P - 2)
 
 
 def root_of_unity(log_n: int) -> int:      # src/babybear.rs:118-126
@@ -94,71 +78,27 @@ def derive_z(tr: Transcript, lde_size: int) -> int:
             return z
 
 
-def poly_eval(coeffs: torch.Tensor, z: int) -> int:
-    """sum c_i z^i on the device (int64 tensor of coefficients): powers by doubling, products < 2^62, partial sums < 2^53."""
-    n = coeffs.numel()
-    pw = torch.ones(1, dtype=torch.int64, device=coeffs.device)
-    step = z % P
-    while pw.numel() < n:
-        pw = torch.cat([pw, mulmod(pw, step)])
-        step = step * step % P
-    return int((mulmod(coeffs, pw[:n]).sum() % P).item())
-
-
 class DeviceTree:
-    """Merkle tree built and kept on the device (toyni_merkle_commit_device); src/fibonacci.rs:340-361."""
+    """Merkle tree built and kept on the device (src/fibonacci.rs:340-361).  `levels` may already hold the tree (a FRI round's
+    fold + commit wrote it); otherwise it is built here."""
 
-    def __init__(self, values_i32: torch.Tensor, rng, salted: bool, stream: int):
+    def __init__(self, values_i32: torch.Tensor, salts, stream: int, levels=None):
         n = values_i32.numel()
         self.n = n
         self.values = values_i32
-        self.salts = None
-        d_salts = 0
-        if salted:
-            self.salts = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device=values_i32.device, generator=rng)
-            d_salts = self.salts.data_ptr()
-        total = _lib.toyni_merkle_total_digests(n)
-        self.levels = torch.empty((total, 32), dtype=torch.uint8, device=values_i32.device)
-        toyni_amd.merkle_commit_device(values_i32.data_ptr(), d_salts, n, self.levels.data_ptr(), stream=stream)
-        self.offsets, off, m = [], 0, n
-        while True:
-            self.offsets.append((off, m))
-            if m == 1:
-                break
-            off += m
-            m = (m + 1) // 2
+        self.salts = salts
+        if levels is None:
+            levels = torch.empty((_lib.toyni_merkle_total_digests(n), 32), dtype=torch.uint8, device=values_i32.device)
+            toyni_amd.merkle_commit_device(values_i32.data_ptr(), salts.data_ptr() if salts is not None else 0, n, levels.data_ptr(), stream=stream)
+        self.levels = levels
 
     def root(self) -> bytes:
-        return bytes(self.levels[-1].cpu().numpy().tobytes())
+        return bytes(self.levels[-1].cpu().numpy().tobytes())       # 32 bytes D2H (synchronises the stream)
 
-    def open_many(self, indices):
-        """open_merkle (src/fibonacci.rs:366-375) + MerkleTree::get_proof (src/merkle.rs:50-80) for a list of positions:
-        ONE gather of all path digests / values / salts on the device, one copy to the host."""
-        rows, positions = [], []
-        for index in indices:
-            pos, cur = [], index
-            for off, m in self.offsets[:-1]:
-                sib = cur + 1 if cur % 2 == 0 else cur - 1
-                if sib >= m:
-                    rows.append(off + cur)
-                    pos.append(True)
-                else:
-                    rows.append(off + sib)
-                    pos.append(cur % 2 == 1)
-                cur //= 2
-            positions.append(pos)
-        dev = self.levels.device
-        idx_t = torch.tensor(list(indices), dtype=torch.long, device=dev)
-        depth = len(self.offsets) - 1
-        paths = self.levels[torch.tensor(rows, dtype=torch.long, device=dev)].cpu().numpy().reshape(len(indices), depth, 32) if rows \
-            else np.zeros((len(indices), 0, 32), np.uint8)
-        vals = self.values[idx_t].cpu().numpy()
-        salts = self.salts[idx_t].cpu().numpy() if self.salts is not None else None
-        return [{"index": index, "value": int(vals[k]), "path": [p.tobytes() for p in paths[k]], "position": positions[k],
-                 "salt": salts[k].tobytes() if salts is not None else b""} for k, index in enumerate(indices)]
-
-    def open(self, index: int):
-        return self.open_many([index])[0]
+    def open_into(self, d_indices: int, count: int, d_out: int, stream: int) -> None:
+        """open_merkle (src/fibonacci.rs:366-375) for `count` positions: paths, salts and values gathered by one kernel."""
+        toyni_amd.prover.merkle_open_device(self.levels.data_ptr(), self.n, self.values.data_ptr(),
+                                            self.salts.data_ptr() if self.salts is not None else 0, d_indices, count, d_out, stream=stream)
 
 
 def fibonacci_trace(n: int) -> np.ndarray:
@@ -171,7 +111,9 @@ def fibonacci_trace(n: int) -> np.ndarray:
     return out
 
 
-def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, timing: dict = None):
+def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, timing: dict = None, raw: bool = False):
+    """raw=True returns the proof with its openings still in the serialized record form the device wrote (what a prover would
+    put on the wire; `expand_proof` turns it into the field-by-field structure of StarkProof / QueryProof)."""
     import time
     dev = torch.device("cuda", 0)
     _t = [time.perf_counter()]
@@ -194,53 +136,47 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     g = root_of_unity(log_n)                       # domain.group_gen()
     ctx_n = toyni_amd.ntt.get_or_create_ctx(n)
     ctx_N = toyni_amd.ntt.get_or_create_ctx(N)
+    pv = toyni_amd.prover
+    bound = 1 << (n + MASK_DEGREE - 1).bit_length()               # fri_degree_bound = next_power_of_two, src/fibonacci.rs:218
+    final_size = N // bound
+    # every salt of the proof in one draw: 3 LDE-size trees + the salted FRI layers (16 bytes per leaf, src/fibonacci.rs:341-343)
+    salted_leaves = 3 * N + sum(N >> k for k in range(1, 64) if (N >> k) > final_size)
+    salt_pool = torch.randint(0, 256, (salted_leaves, 16), dtype=torch.uint8, device=dev, generator=rng)
+    salt_off = [0]
+
+    def take_salts(count):
+        sl = salt_pool[salt_off[0]:salt_off[0] + count]
+        salt_off[0] += count
+        return sl
 
     def ntt_dev(ctx, t32, inverse, shift=1):
         ctx.run_device(t32.data_ptr(), t32.data_ptr(), 1, inverse, stream=stream, shift=shift)
 
     # ---- 1. trace polynomial + masking (src/fibonacci.rs:110-121): T_hat = T + (x^n - 1) R ----
-    coeffs = torch.from_numpy(trace_col.astype(np.int32)).to(dev)
-    ntt_dev(ctx_n, coeffs, True)                                   # interpolate: one INTT
-    r = torch.randint(0, P, (MASK_DEGREE,), dtype=torch.int64, device=dev, generator=rng)
-    poly = torch.zeros(N, dtype=torch.int64, device=dev)
-    poly[:n] = coeffs.to(torch.int64)
-    poly[:MASK_DEGREE] = (poly[:MASK_DEGREE] - r) % P
-    poly[n:n + MASK_DEGREE] = (poly[n:n + MASK_DEGREE] + r) % P
-    trace_poly = poly[: n + MASK_DEGREE].clone()                  # coefficients, for the OOD evaluations
-    # LDE: one coset FFT of the masked polynomial (n + MASK_DEGREE coefficients); the zero padding up to N is
-    # implied, not stored (toyni_lde_device: the first pass reads only the words that exist)
     log_c = (n + MASK_DEGREE - 1).bit_length()                     # compact length 2^log_c >= n + MASK_DEGREE
     assert log_c <= log_N
-    compact = poly[: 1 << log_c].to(torch.int32).contiguous()
+    compact = torch.zeros(1 << log_c, dtype=torch.int32, device=dev)
+    compact[:n] = torch.from_numpy(trace_col.astype(np.int32)).to(dev)
+    ctx_n.run_device(compact.data_ptr(), compact.data_ptr(), 1, True, stream=stream)      # interpolate: one INTT
+    r = torch.randint(0, P, (MASK_DEGREE,), dtype=torch.int64, device=dev, generator=rng)
+    compact[:MASK_DEGREE] = ((compact[:MASK_DEGREE].to(torch.int64) - r) % P).to(torch.int32)           # - R
+    compact[n:n + MASK_DEGREE] = ((compact[n:n + MASK_DEGREE].to(torch.int64) + r) % P).to(torch.int32)  # + x^n R
+    ncoef_t = n + MASK_DEGREE                                      # trace_poly = compact[:ncoef_t], for the OOD evaluations
+    # LDE: one coset FFT of the masked polynomial; the zero padding up to N is implied (toyni_lde_device)
     trace_lde = torch.empty(N, dtype=torch.int32, device=dev)
     ctx_N.lde_device(compact.data_ptr(), trace_lde.data_ptr(), 1, log_N - log_c, COSET_SHIFT, stream=stream)
-    trace_tree = DeviceTree(trace_lde, rng, True, stream)
-    trace_commitment = trace_tree.root()
+    trace_tree = DeviceTree(trace_lde, take_salts(N), stream)
     lap("1_interpolate_mask_lde_commit")
 
-    # x_i = 7 w_N^i
-    xs32 = torch.empty(N, dtype=torch.int32, device=dev)
-    ctx_N.domain_elements_device(xs32.data_ptr(), N, COSET_SHIFT, stream=stream)   # lde_domain.elements(), src/fibonacci.rs:133
-    xs = xs32.to(torch.int64)
-
-    # ---- 2. constraint & quotient (src/fibonacci.rs:133-153) ----
-    T = trace_lde.to(torch.int64)
-    T_g = torch.roll(T, -BLOWUP)                                   # T(g x_i) = trace_lde[(i + BLOWUP) % N]
-    T_gg = torch.roll(T, -2 * BLOWUP)
-    fib = (T_gg - T_g - T) % P
-    b1 = (xs - pow(g, n - 1, P)) % P
-    b2 = (xs - pow(g, n - 2, P)) % P
-    c_evals = mulmod(mulmod(fib, b1), b2)
-    c32 = c_evals.to(torch.int32)
-    c_poly = c32.clone()
-    ntt_dev(ctx_N, c_poly, True, shift=COSET_SHIFT)                # ifft #1 (c_poly; re-evaluating it on the coset is the identity)
-    zh = (powmod_t(xs, n) - 1) % P                                 # Z_H(x_i) = x_i^n - 1
-    q_evals = mulmod(c_evals, invmod_t(zh))
-    q32 = q_evals.to(torch.int32)
-    q_poly_t = q32.clone()
-    ntt_dev(ctx_N, q_poly_t, True, shift=COSET_SHIFT)              # ifft #2
-    q_poly = q_poly_t.to(torch.int64)
-    quotient_tree = DeviceTree(q32, rng, True, stream)
+    # ---- 2. constraint & quotient (src/fibonacci.rs:133-153): one kernel; then the reference's two ifft calls ----
+    c32 = torch.empty(N, dtype=torch.int32, device=dev)
+    q32 = torch.empty(N, dtype=torch.int32, device=dev)
+    pv.fib_quotient_device(ctx_N, trace_lde.data_ptr(), c32.data_ptr(), q32.data_ptr(), 5, COSET_SHIFT, stream=stream)
+    ntt_dev(ctx_N, c32, True, shift=COSET_SHIFT)                   # ifft #1 (c_poly; re-evaluating it on the coset is the identity)
+    q_poly = q32.clone()
+    ntt_dev(ctx_N, q_poly, True, shift=COSET_SHIFT)                # ifft #2
+    quotient_tree = DeviceTree(q32, take_salts(N), stream)
+    trace_commitment = trace_tree.root()
     quotient_commitment = quotient_tree.root()
     lap("2_constraint_quotient_commit")
 
@@ -249,56 +185,91 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     tr.absorb(trace_commitment)
     tr.absorb(quotient_commitment)
     z = derive_z(tr, N)
-    t_z, t_gz, t_ggz = poly_eval(trace_poly, z), poly_eval(trace_poly, g * z % P), poly_eval(trace_poly, g * g % P * z % P)
-    q_z = poly_eval(q_poly, z)
+    ood_dev = torch.empty(4, dtype=torch.int32, device=dev)
+    pv.poly_eval_device(ctx_N, compact.data_ptr(), ncoef_t, [z, g * z % P, g * g % P * z % P], ood_dev.data_ptr(), stream=stream)
+    pv.poly_eval_device(ctx_N, q_poly.data_ptr(), N, [z], ood_dev.data_ptr() + 12, stream=stream)
+    t_z, t_gz, t_ggz, q_z = (int(v) for v in ood_dev.cpu().numpy().view(np.uint32))
     c_z = (t_ggz - t_gz - t_z) % P * ((z - pow(g, n - 1, P)) % P) % P * ((z - pow(g, n - 2, P)) % P) % P
     assert c_z == q_z * ((pow(z, n, P) - 1) % P) % P, "Constraint check at z failed"      # src/fibonacci.rs:173-177
     for v in (t_z, t_gz, t_ggz, q_z):
         tr.absorb_field(v)
     lap("3_transcript_ood")
 
-    # ---- 5. DEEP layer (src/fibonacci.rs:186-198) ----
-    inv_xz = invmod_t((xs - z) % P)
-    d_evals = mulmod(((q_evals - q_z) + (T_gg - t_ggz) + (T_g - t_gz) + (T - t_z)) % P, inv_xz)
-
+    # ---- 5. DEEP layer (src/fibonacci.rs:186-198): one kernel ----
+    d32 = torch.empty(N, dtype=torch.int32, device=dev)
+    pv.fib_deep_device(ctx_N, trace_lde.data_ptr(), q32.data_ptr(), d32.data_ptr(), 5, COSET_SHIFT, z, [t_z, t_gz, t_ggz, q_z], stream=stream)
     lap("5_deep")
 
-    # ---- 6. FRI: fold + commit (src/fibonacci.rs:200-247) ----
-    bound = 1 << (n + MASK_DEGREE - 1).bit_length()               # next_power_of_two
-    final_size = N // bound
-    layers = [d_evals.to(torch.int32)]
-    trees = [DeviceTree(layers[0], rng, True, stream)]
+    # ---- 6. FRI: fold + commit, one device call per round (src/fibonacci.rs:200-247) ----
+    layers = [d32]
+    trees = [DeviceTree(d32, take_salts(N), stream)]
     commitments = [trees[0].root()]
     tr.absorb(commitments[0])
     x0 = COSET_SHIFT
     while layers[-1].numel() > final_size:
-        beta = tr.squeeze_challenge()
+        beta = tr.squeeze_challenge()                              # depends on the previous round's root: rounds cannot be merged
         cur = layers[-1]
         m = cur.numel()
-        folded = torch.empty(m // 2, dtype=torch.int32, device=dev)
-        toyni_amd.fri_fold_device(ctx_N, cur.data_ptr(), folded.data_ptr(), m, beta, x0, stream=stream)
+        half = m // 2
+        folded = torch.empty(half, dtype=torch.int32, device=dev)
+        salts = take_salts(half) if half != final_size else None   # the final layer is committed unsalted, :234-238
+        levels = torch.empty((_lib.toyni_merkle_total_digests(half), 32), dtype=torch.uint8, device=dev)
+        pv.fri_fold_commit_device(ctx_N, cur.data_ptr(), folded.data_ptr(), m, beta, x0, salts.data_ptr() if salts is not None else 0,
+                                  levels.data_ptr(), stream=stream)
         x0 = x0 * x0 % P                                          # xs truncated and squared, src/fibonacci.rs:228-231
         layers.append(folded)
-        trees.append(DeviceTree(folded, rng, folded.numel() != final_size, stream))
+        trees.append(DeviceTree(folded, salts, stream, levels=levels))
         commitments.append(trees[-1].root())
         tr.absorb(commitments[-1])
-    final_layer = [int(v) for v in layers[-1].cpu().numpy()]
+    final_layer = [int(v) for v in layers[-1].cpu().numpy().view(np.uint32)]
     lap("6_fri_fold_commit")
 
-    # ---- 7. queries (src/fibonacci.rs:249-295) ----
+    # ---- 7. queries (src/fibonacci.rs:249-295): every opening of the proof gathered on the device, ONE copy to the host ----
     half0 = N // 2
     qidx = tr.squeeze_indices(NUM_QUERIES, half0)
-    t_open = trace_tree.open_many([i for qi in qidx for i in (qi, (qi + BLOWUP) % N, (qi + 2 * BLOWUP) % N)])
-    q_open = quotient_tree.open_many(qidx)
-    d_open = trees[0].open_many([i for qi in qidx for i in (qi, qi + half0)])
-    fri_open = []                                   # per intermediate layer: openings of (idx, idx + half) for every query
-    cur_idx = list(qidx)
+    q = np.asarray(qidx, dtype=np.int64)
+    groups = [(trace_tree, np.stack([q, (q + BLOWUP) % N, (q + 2 * BLOWUP) % N], axis=1).reshape(-1)),     # T(x), T(g x), T(g^2 x)
+              (quotient_tree, q),
+              (trees[0], np.stack([q, q + half0], axis=1).reshape(-1))]                                   # DEEP layer: qi and its pair
+    cur_idx = q.copy()
     for li in range(1, len(layers) - 1):
         half = layers[li].numel() // 2
-        cur_idx = [i % half for i in cur_idx]
-        fri_open.append(trees[li].open_many([j for i in cur_idx for j in (i, i + half)]))
+        cur_idx = cur_idx % half
+        groups.append((trees[li], np.stack([cur_idx, cur_idx + half], axis=1).reshape(-1)))
+    all_idx = np.concatenate([ix for _, ix in groups]).astype(np.int32)
+    d_idx = torch.from_numpy(all_idx).to(dev)
+    sizes = [ix.size * pv.merkle_open_record_bytes(t.n) for t, ix in groups]
+    out = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    ioff = boff = 0
+    for (t, ix), sz in zip(groups, sizes):
+        t.open_into(d_idx.data_ptr() + 4 * ioff, ix.size, out.data_ptr() + boff, stream)
+        ioff += ix.size
+        boff += sz
+    records = out.cpu().numpy()
+    lap("7_queries")
+    if stats is not None:
+        stats.update({"n": n, "lde": N, "folds": len(layers) - 1, "final_layer_size": final_size})
+    proof = {
+        "trace_len": n, "lde_size": N, "trace_commitment": trace_commitment, "quotient_commitment": quotient_commitment,
+        "t_z": t_z, "t_gz": t_gz, "t_ggz": t_ggz, "q_z": q_z, "fri_commitments": commitments, "fri_final_layer": final_layer,
+        "query_indices": qidx,
+        "opening_records": records,                                   # serialized openings, in the group order above
+        "opening_groups": [(t.n, t.salts is not None, ix.tolist()) for t, ix in groups],
+    }
+    return proof if raw else expand_proof(proof)
+
+
+def expand_proof(proof):
+    """Serialized opening records -> the QueryProof structure of src/fibonacci.rs:73-87 (what the verifier restatement reads)."""
+    pv = toyni_amd.prover
+    parsed, off = [], 0
+    for tn, salted, idx in proof["opening_groups"]:
+        sz = len(idx) * pv.merkle_open_record_bytes(tn)
+        parsed.append(pv.parse_openings(proof["opening_records"][off:off + sz], tn, idx, salted))
+        off += sz
+    t_open, q_open, d_open, fri_open = parsed[0], parsed[1], parsed[2], parsed[3:]
     query_proofs = []
-    for k, qi in enumerate(qidx):
+    for k, qi in enumerate(proof["query_indices"]):
         query_proofs.append({
             "index": qi,
             "trace_opening": t_open[3 * k], "trace_opening_g": t_open[3 * k + 1], "trace_opening_gg": t_open[3 * k + 2],
@@ -306,12 +277,6 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
             "deep_opening": d_open[2 * k], "deep_opening_pair": d_open[2 * k + 1],
             "fri_openings": [(lo[2 * k], lo[2 * k + 1]) for lo in fri_open],
         })
-
-    lap("7_queries")
-    if stats is not None:
-        stats.update({"n": n, "lde": N, "folds": len(layers) - 1, "final_layer_size": final_size})
-    return {
-        "trace_len": n, "lde_size": N, "trace_commitment": trace_commitment, "quotient_commitment": quotient_commitment,
-        "t_z": t_z, "t_gz": t_gz, "t_ggz": t_ggz, "q_z": q_z, "fri_commitments": commitments, "fri_final_layer": final_layer,
-        "query_proofs": query_proofs,
-    }
+    out = {k: v for k, v in proof.items() if k not in ("opening_records", "opening_groups", "query_indices")}
+    out["query_proofs"] = query_proofs
+    return out

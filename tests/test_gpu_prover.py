@@ -1,0 +1,133 @@
+"""GPU parity of the pointwise prover kernels and the fused FRI round (include/toyni_hip.h 3c) against the oracle's restatements
+of src/fibonacci.rs:133-150,186-198,222-245, src/math/polynomial.rs:134-144 and src/merkle.rs:50-80 -- bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.init()
+    import toyni_amd
+    return toyni_amd, torch, torch.device("cuda", 0)
+
+
+def _dev(torch, dev, arr_u64):
+    return torch.from_numpy(np.asarray(arr_u64, dtype=np.uint64).astype(np.uint32).view(np.int32)).to(dev)
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint32).astype(np.uint64)
+
+
+@pytest.mark.parametrize("log_N,log_blowup,shift", [(6, 2, 7), (8, 5, 7), (10, 3, 1234567), (16, 5, 7), (21, 5, 7), (3, 1, 7), (5, 0, 7)])
+def test_quotient_and_deep(env, log_N, log_blowup, shift):
+    ta, torch, dev = env
+    N, n = 1 << log_N, (1 << log_N) >> log_blowup
+    if n < 2:
+        pytest.skip("trace of one row")
+    ctx = ta.ntt.get_or_create_ctx(N)
+    lde = oracle.splitmix(N, 9000 + log_N)
+    c_want, q_want = oracle.fib_quotient(lde, n, shift)
+    t = _dev(torch, dev, lde)
+    c = torch.empty_like(t)
+    q = torch.empty_like(t)
+    ta.prover.fib_quotient_device(ctx, t.data_ptr(), c.data_ptr(), q.data_ptr(), log_blowup, shift)
+    torch.cuda.synchronize()
+    assert (_host(c) == c_want).all() and (_host(q) == q_want).all()
+    q2 = torch.empty_like(t)
+    ta.prover.fib_quotient_device(ctx, t.data_ptr(), 0, q2.data_ptr(), log_blowup, shift)       # c_evals optional
+    z, ood = 987654321, [5, P - 1, 0, 123456789]
+    d_want = oracle.fib_deep(lde, q_want, n, shift, z, *ood)
+    d = torch.empty_like(t)
+    ta.prover.fib_deep_device(ctx, t.data_ptr(), q2.data_ptr(), d.data_ptr(), log_blowup, shift, z, ood)
+    torch.cuda.synchronize()
+    assert (_host(d) == d_want).all()
+
+
+def test_quotient_rejects_a_coset_on_which_z_h_vanishes(env):
+    ta, torch, dev = env
+    ctx = ta.ntt.get_or_create_ctx(64)
+    t = torch.zeros(64, dtype=torch.int32, device=dev)
+    with pytest.raises(ta._lib.ToyniError, match="Cannot invert zero"):                            # shift = 1: x^n - 1 = 0 on the trace domain
+        ta.prover.fib_quotient_device(ctx, t.data_ptr(), 0, t.data_ptr(), 3, 1)
+
+
+@pytest.mark.parametrize("ncoeffs", [0, 1, 15, 16, 17, 4095, 4096, 4097, 65536 + 140, 1 << 21])
+def test_poly_eval(env, ncoeffs):
+    ta, torch, dev = env
+    ctx = ta.ntt.get_or_create_ctx(1 << 10)
+    c = oracle.splitmix(max(ncoeffs, 1), 31 + ncoeffs)[:ncoeffs]
+    t = _dev(torch, dev, c if ncoeffs else np.zeros(1, dtype=np.uint64))
+    pts = [123456789, 0, 1, P - 1]
+    out = torch.zeros(4, dtype=torch.int32, device=dev)
+    ta.prover.poly_eval_device(ctx, t.data_ptr(), ncoeffs, pts, out.data_ptr())
+    torch.cuda.synchronize()
+    assert _host(out).tolist() == [oracle.poly_eval(c, x) for x in pts]
+    out1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    ta.prover.poly_eval_device(ctx, t.data_ptr(), ncoeffs, pts[:1], out1.data_ptr())
+    torch.cuda.synchronize()
+    assert int(_host(out1)[0]) == oracle.poly_eval(c, pts[0])
+
+
+@pytest.mark.parametrize("n,salted", [(1, True), (2, False), (3, True), (13, True), (1000, False), (1 << 12, True), (1 << 16, True)])
+def test_merkle_openings(env, n, salted):
+    ta, torch, dev = env
+    lib = ta._lib.lib
+    vals = oracle.splitmix(n, 77 + n)
+    salts = np.random.default_rng(n).integers(0, 256, (n, 16), dtype=np.uint8) if salted else None
+    levels_want = oracle.merkle_commit_values(vals, salts)
+    v = _dev(torch, dev, vals)
+    s = torch.from_numpy(salts).to(dev) if salted else None
+    lv = torch.empty((lib.toyni_merkle_total_digests(n), 32), dtype=torch.uint8, device=dev)
+    ta.merkle_commit_device(v.data_ptr(), s.data_ptr() if salted else 0, n, lv.data_ptr())
+    idx = sorted(set([0, n - 1, n // 2, (n * 7) // 11] + list(np.random.default_rng(1).integers(0, n, 10))))
+    it = torch.tensor(idx, dtype=torch.int32, device=dev)
+    rec = ta.prover.merkle_open_record_bytes(n)
+    out = torch.zeros(len(idx) * rec, dtype=torch.uint8, device=dev)
+    ta.prover.merkle_open_device(lv.data_ptr(), n, v.data_ptr(), s.data_ptr() if salted else 0, it.data_ptr(), len(idx), out.data_ptr())
+    torch.cuda.synchronize()
+    ops = ta.prover.parse_openings(out.cpu().numpy(), n, idx, salted)
+    for o in ops:
+        path, pos = oracle.merkle_get_proof(levels_want, o["index"])
+        assert o["path"] == path and o["position"] == pos and o["value"] == int(vals[o["index"]])
+        assert o["salt"] == (salts[o["index"]].tobytes() if salted else b"")
+
+
+@pytest.mark.parametrize("log_m,salted", [(1, False), (2, True), (5, True), (11, True), (12, False), (16, True), (21, True)])
+def test_fold_commit_round(env, log_m, salted):
+    """One protocol round (src/fibonacci.rs:222-245): layer values as fri_fold, tree as build_merkle_tree of the folded layer."""
+    ta, torch, dev = env
+    lib = ta._lib.lib
+    m = 1 << log_m
+    ctx = ta.ntt.get_or_create_ctx(max(m, 2))
+    e = oracle.splitmix(m, 500 + log_m)
+    beta, x0 = 424242 + log_m, 49
+    xs = oracle.domain_elements(m, x0)
+    want = oracle.fri_fold(e, xs, beta)
+    half = m // 2
+    salts = np.random.default_rng(log_m).integers(0, 256, (half, 16), dtype=np.uint8) if salted else None
+    levels_want = np.concatenate(oracle.merkle_commit_values(want, salts))
+    te = _dev(torch, dev, e)
+    out = torch.empty(half, dtype=torch.int32, device=dev)
+    s = torch.from_numpy(salts).to(dev) if salted else None
+    lv = torch.zeros((lib.toyni_merkle_total_digests(half), 32), dtype=torch.uint8, device=dev)
+    ta.prover.fri_fold_commit_device(ctx, te.data_ptr(), out.data_ptr(), m, beta, x0, s.data_ptr() if salted else 0, lv.data_ptr())
+    torch.cuda.synchronize()
+    assert (_host(out) == want).all()
+    assert (lv.cpu().numpy() == levels_want).all()
+    # and identical to the two separate calls it replaces
+    out2 = torch.empty_like(out)
+    lv2 = torch.zeros_like(lv)
+    ta.fri_fold_device(ctx, te.data_ptr(), out2.data_ptr(), m, beta, x0)
+    ta.merkle_commit_device(out2.data_ptr(), s.data_ptr() if salted else 0, half, lv2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(lv, lv2)

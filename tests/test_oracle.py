@@ -204,3 +204,73 @@ def test_merkle_golden(golden):
         salts = np.frombuffer(b"".join(bytes.fromhex(s) for s in c["salts_hex"]), dtype=np.uint8).reshape(c["n"], 16)
         assert oracle.merkle_commit_values(c["values"], None)[-1][0].tobytes().hex() == c["root_unsalted"]
         assert oracle.merkle_commit_values(c["values"], salts)[-1][0].tobytes().hex() == c["root_salted"]
+
+
+# ---- pointwise prover steps (round 2): pinned on an independent model that follows the reference LITERALLY --------------
+# src/fibonacci.rs:133-150,186-198 evaluate the trace polynomial by Horner at x, g x and g^2 x for every coset point; the
+# oracle's restatement reads the LDE at positions i, i + B, i + 2B instead.  The model below does it the reference's way
+# (python ints, Polynomial::evaluate per point), so the identity the restatement relies on is itself under test.
+def _horner(coeffs, x):
+    r = 0
+    for c in reversed(coeffs):
+        r = (r * x + c) % P
+    return r
+
+
+def test_fib_quotient_and_deep_match_the_reference_formulas():
+    import random
+    rnd = random.Random(5)
+    for n, blow in ((8, 4), (16, 32), (4, 8)):
+        N = n * blow
+        shift = 7
+        g = oracle.root_of_unity(n.bit_length() - 1)
+        w = oracle.root_of_unity(N.bit_length() - 1)
+        xs = [shift * pow(w, i, P) % P for i in range(N)]
+        tpoly = [rnd.randrange(P) for _ in range(n + 3)]                       # a masked trace polynomial: degree >= n
+        lde = [_horner(tpoly, x) for x in xs]
+        b1, b2 = pow(g, n - 1, P), pow(g, n - 2, P)
+        c_ref, q_ref = [], []
+        for x in xs:
+            fib = (_horner(tpoly, g * g * x % P) - (_horner(tpoly, g * x % P) + _horner(tpoly, x))) % P
+            c = fib * ((x - b1) % P) % P * ((x - b2) % P) % P
+            c_ref.append(c)
+            q_ref.append(c * pow((pow(x, n, P) - 1) % P, P - 2, P) % P)
+        c, q = oracle.fib_quotient(lde, n, shift)
+        assert c.tolist() == c_ref and q.tolist() == q_ref, (n, blow)
+        z = rnd.randrange(P)
+        t_z, t_gz, t_ggz, q_z = (rnd.randrange(P) for _ in range(4))            # any values: the formula is checked, not the protocol
+        d_ref = []
+        for i, x in enumerate(xs):
+            inv = pow((x - z) % P, P - 2, P)
+            d_ref.append(((q_ref[i] - q_z) * inv + (_horner(tpoly, g * g * x % P) - t_ggz) * inv
+                          + (_horner(tpoly, g * x % P) - t_gz) * inv + (lde[i] - t_z) * inv) % P)
+        assert oracle.fib_deep(lde, q, n, shift, z, t_z, t_gz, t_ggz, q_z).tolist() == d_ref, (n, blow)
+
+
+def test_poly_eval_is_horner():
+    import random
+    rnd = random.Random(6)
+    assert oracle.poly_eval([], 5) == 0                                          # src/math/polynomial.rs:135-137
+    for deg in (0, 1, 2, 17, 300):
+        c = [rnd.randrange(P) for _ in range(deg + 1)]
+        for x in (0, 1, P - 1, rnd.randrange(P)):
+            assert oracle.poly_eval(c, x) == _horner(c, x)
+
+
+def test_merkle_get_proof_verifies_like_the_reference():
+    # src/merkle.rs:50-101: every proof of every leaf verifies against the root, odd level sizes included; a wrong leaf does not
+    for n in (1, 2, 3, 5, 8, 13):
+        vals = np.arange(10, 10 + n, dtype=np.uint64)
+        salts = (np.arange(n * 16, dtype=np.uint32) * 37 % 251).astype(np.uint8).reshape(n, 16)
+        for s in (None, salts):
+            lv = oracle.merkle_commit_values(vals, s)
+            root = lv[-1][0].tobytes()
+            for i in range(n):
+                path, pos = oracle.merkle_get_proof(lv, i)
+                leaf = (s[i].tobytes() if s is not None else b"") + int(vals[i]).to_bytes(8, "little")
+                for tamper in (False, True):
+                    cur = oracle.hash_leaf(leaf if not tamper else leaf[:-1] + b"\x7f")
+                    for sib, right in zip(path, pos):
+                        cur = oracle.hash_node(sib, cur) if right else oracle.hash_node(cur, sib)
+                    assert (cur == root) == (not tamper)
+            assert oracle.merkle_get_proof(lv, n) is None

@@ -7,9 +7,12 @@
 set -u
 TAG=${1:-r01}
 BATCH=${2:-1024}
-OUT=gpurun_out/profiles_$TAG
+LOGN=${3:-20}
+SUFFIX=""
+[ "$LOGN" != "20" ] && SUFFIX="_2p$LOGN"
+OUT=gpurun_out/profiles_$TAG$SUFFIX
 mkdir -p $OUT
-CMD="python3 bench.py --steps 3 --warmup 1 --batch $BATCH --no-extras --no-cpu-baseline"
+CMD="python3 bench.py --steps 3 --warmup 1 --log-n $LOGN --batch $BATCH --no-extras --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 || exit 1

@@ -16,7 +16,9 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-src = f"gpurun_out/profiles_{tag}"
+log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+suffix = "" if log_n == 20 else f"_2p{log_n}"          # profiles/<tag>_traffic_2p24.json etc. for the other headline size
+src = f"gpurun_out/profiles_{tag}{suffix}"
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -36,18 +38,18 @@ def counters(sub):
 
 stats = newest(f"{src}/stats/*/*kernel_stats.csv")
 if stats:
-    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats{suffix}.csv")
 allc = {}
 for sub in ("fetch", "write", "sq", "lds"):
     for k, v in counters(sub).items():
         allc.setdefault(k, {}).update(v)
-json.dump(allc, open(f"profiles/{tag}_counters.json", "w"), indent=1, sort_keys=True)
+json.dump(allc, open(f"profiles/{tag}_counters{suffix}.json", "w"), indent=1, sort_keys=True)
 
 durations = {}
 if stats:
     for r in csv.DictReader(open(stats[0])):
         durations[r["Name"]] = float(r["AverageNs"])
-traffic = {"log_n": 20, "batch_per_gpu": batch, "command": f"python3 bench.py --steps 3 --warmup 1 --batch {batch} --no-extras --no-cpu-baseline",
+traffic = {"log_n": log_n, "batch_per_gpu": batch, "command": f"python3 bench.py --steps 3 --warmup 1 --log-n {log_n} --batch {batch} --no-extras --no-cpu-baseline",
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "kernels": {}}
 for k, v in allc.items():
     if "ntt_pass_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -56,8 +58,8 @@ for k, v in allc.items():
             "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
             "rocprof_avg_ns": durations.get(k),
         }
-json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump(traffic, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1, sort_keys=True)
 bj = f"{src}/bench_under_rocprof.json"
 if os.path.exists(bj) and os.path.getsize(bj):
-    shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof.json")
+    shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof{suffix}.json")
 print(json.dumps(traffic, indent=1)[:1500])

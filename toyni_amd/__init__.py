@@ -14,5 +14,6 @@ from .ntt import (  # noqa: F401
 from .fri import fri_fold, fri_fold_device, fri_fold_ext, fri_fold_ext_device, fri_fold_layers_device  # noqa: F401
 from .domain import BabyBearDomain  # noqa: F401
 from .merkle import MerkleTree, merkle_commit_device  # noqa: F401
+from . import prover  # noqa: F401
 
 P = 2013265921

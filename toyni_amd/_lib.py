@@ -97,6 +97,13 @@ SIGNATURES = {
     "toyni_merkle_total_digests": (c_size, [c_size]),
     "toyni_merkle_commit_device": (c_int, [c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
     "toyni_merkle_commit_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    # section 3c
+    "toyni_fri_fold_commit_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p, c_void_p, c_void_p]),
+    "toyni_fib_quotient_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
+    "toyni_fib_deep_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_u32, c_void_p, c_void_p]),
+    "toyni_poly_eval_device": (c_int, [c_void_p, c_void_p, c_size, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
+    "toyni_merkle_open_record_bytes": (c_size, [c_size]),
+    "toyni_merkle_open_device": (c_int, [c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
     # section 4
     "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
     "toyni_free": (c_int, [c_void_p]),

@@ -150,7 +150,9 @@ inline int& pass3_max_log_tiles32() {
 
 template <class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
-    if (log_tiles32 <= pass3_max_log_tiles32()) {
+    // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
+    // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
+    if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
 #define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false>{}); return true; }
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 2)
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 3)
@@ -214,7 +216,7 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
         default: return false;                                                               \
     }
 #define TOYNI_COMMA ,
-    if (log_tiles32 <= pass3_max_log_tiles32()) {
+    if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
         if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
         if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
         if (log_m == 10) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }

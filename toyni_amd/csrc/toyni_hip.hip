@@ -14,6 +14,7 @@
 #include "toyni_hip.h"  // include/toyni_hip.h: -I include here; next to this file in a crate's hip/ directory
 #include "ntt_plan.hpp"
 #include "merkle_kernels.hpp"
+#include "prover_kernels.hpp"
 
 using namespace toyni;
 
@@ -267,8 +268,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the non-tem
 
 // FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows.
 // NT: non-temporal accesses for layers far larger than the Infinity Cache (read once, written once).
-template <bool NT>
-__global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
+// COMMIT: the same sweep also hashes the leaves of the FOLDED layer's Merkle tree (src/fibonacci.rs:233-241: the layer is
+// committed right after it is folded), so the new layer is produced and leaf-hashed in one pass over the old one:
+// leaves[i] = SHA256(0x00 || salt_i || out[i]) (salts == nullptr: the unsalted final-layer form).
+template <bool NT, bool COMMIT = false>
+__global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f, const uint4* __restrict__ salts = nullptr, Digest* __restrict__ leaves = nullptr) {
     const uint64_t half = f.half;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     if ((half & 3) == 0) {
@@ -297,10 +301,160 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f) {
             } else {
                 o[q] = r;
             }
+            if constexpr (COMMIT) {
+                const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (salts) {
+                        const uint4 sv = salts[4 * q + j];
+                        const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                        leaves[4 * q + j] = merkle_leaf(rv[j], sw);
+                    } else {
+                        leaves[4 * q + j] = merkle_leaf(rv[j], nullptr);
+                    }
+                }
+            }
         }
     } else {
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride)
-            f.out[i] = fold_one(f, i, f.evals[i], f.evals[i + half]);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
+            const uint32_t r = fold_one(f, i, f.evals[i], f.evals[i + half]);
+            f.out[i] = r;
+            if constexpr (COMMIT) {
+                if (salts) {
+                    const uint4 sv = salts[i];
+                    const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+                    leaves[i] = merkle_leaf(r, sw);
+                } else {
+                    leaves[i] = merkle_leaf(r, nullptr);
+                }
+            }
+        }
+    }
+}
+
+// ---- pointwise prover steps (prover_kernels.hpp) ----
+// constraint + quotient: 4 consecutive points per thread (16-byte accesses; the three trace reads of a point are B and 2B
+// words apart, B = blow-up, so they stay 16-byte aligned when B >= 4); 1 / Z_H per residue class in LDS
+__global__ void __launch_bounds__(256) fib_quotient_kernel(const QuotientArgs a) {
+    __shared__ uint32_t zh_inv[1024];
+    const uint32_t B = 1u << a.log_blowup;
+    for (uint32_t t = threadIdx.x; t < B; t += blockDim.x) zh_inv[t] = quotient_zh_inv(a, t);
+    __syncthreads();
+    const uint64_t N = (uint64_t)1 << a.log_N, mask = N - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (a.log_blowup >= 2 && a.log_N >= 2) {
+        const uint4* tr = reinterpret_cast<const uint4*>(a.trace);
+        for (uint64_t qd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < N / 4; qd += stride) {
+            const uint64_t i = 4 * qd;
+            const uint4 v0 = tr[qd], v1 = tr[((i + B) & mask) >> 2], v2 = tr[((i + 2 * B) & mask) >> 2];
+            const uint32_t t0[4] = {v0.x, v0.y, v0.z, v0.w}, t1[4] = {v1.x, v1.y, v1.z, v1.w}, t2[4] = {v2.x, v2.y, v2.z, v2.w};
+            uint32_t c[4], qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) quotient_one(a, i + j, t0[j], t1[j], t2[j], zh_inv[(i + j) & (B - 1)], c[j], qv[j]);
+            if (a.c_out) reinterpret_cast<uint4*>(a.c_out)[qd] = make_uint4(c[0], c[1], c[2], c[3]);
+            reinterpret_cast<uint4*>(a.q_out)[qd] = make_uint4(qv[0], qv[1], qv[2], qv[3]);
+        }
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+            uint32_t c, qv;
+            quotient_one(a, i, a.trace[i], a.trace[(i + B) & mask], a.trace[(i + 2 * B) & mask], zh_inv[i & (B - 1)], c, qv);
+            if (a.c_out) a.c_out[i] = c;
+            a.q_out[i] = qv;
+        }
+    }
+}
+
+// DEEP layer: 8 consecutive points per thread share one inversion
+__global__ void __launch_bounds__(256) fib_deep_kernel(const DeepArgs a) {
+    constexpr int K = 8;
+    const uint64_t N = (uint64_t)1 << a.log_N, mask = N - 1, B = (uint64_t)1 << a.log_blowup;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (a.log_N >= 3) {
+        for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < N / K; g += stride) {
+            const uint64_t i0 = g * K;
+            uint32_t t0[K], t1[K], t2[K], qv[K], out[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {   // consecutive addresses: the compiler merges them into 16-byte loads when B is a multiple of 4
+                t0[j] = a.trace[i0 + j];
+                t1[j] = a.trace[(i0 + j + B) & mask];
+                t2[j] = a.trace[(i0 + j + 2 * B) & mask];
+                qv[j] = a.quot[i0 + j];
+            }
+            deep_group<K>(a, i0, t0, t1, t2, qv, out);
+#pragma unroll
+            for (int j = 0; j < K; ++j) a.out[i0 + j] = out[j];
+        }
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+            const uint32_t t0[1] = {a.trace[i]}, t1[1] = {a.trace[(i + B) & mask]}, t2[1] = {a.trace[(i + 2 * B) & mask]}, qv[1] = {a.quot[i]};
+            uint32_t out[1];
+            deep_group<1>(a, i, t0, t1, t2, qv, out);
+            a.out[i] = out[0];
+        }
+    }
+}
+
+// block-wide sum mod p through LDS (256 threads)
+__device__ __forceinline__ uint32_t block_sum_mod(uint32_t v, uint32_t* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] = bb_add(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    const uint32_t r = red[0];
+    __syncthreads();
+    return r;
+}
+// polynomial evaluation, stage 1: every block reduces one chunk of POLY_CHUNK coefficients for all points
+__global__ void __launch_bounds__(256) poly_eval_partial_kernel(const PolyEvalArgs a) {
+    __shared__ uint32_t red[256];
+    const uint64_t base = (uint64_t)blockIdx.x * POLY_CHUNK + (uint64_t)threadIdx.x * POLY_PER_THREAD;
+    uint32_t c[POLY_PER_THREAD];
+#pragma unroll
+    for (uint32_t j = 0; j < POLY_PER_THREAD; ++j) c[j] = base + j < a.ncoeffs ? a.coeffs[base + j] : 0u;
+    for (uint32_t p = 0; p < a.npoints; ++p) {
+        const uint32_t sum = block_sum_mod(poly_thread_term(a, p, c, threadIdx.x), red);
+        if (threadIdx.x == 0) a.partial[(uint64_t)blockIdx.x * a.npoints + p] = sum;
+    }
+}
+// stage 2 (one block): out[p] = sum_b partial[b][p] * (z^POLY_CHUNK)^b
+__global__ void __launch_bounds__(256) poly_eval_final_kernel(const PolyEvalArgs a) {
+    __shared__ uint32_t red[256];
+    for (uint32_t p = 0; p < a.npoints; ++p) {
+        uint32_t acc = 0;
+        for (uint32_t b = threadIdx.x; b < a.nblocks; b += blockDim.x)
+            acc = bb_add(acc, mont_mul(a.partial[(uint64_t)b * a.npoints + p], mont_pow(a.zchunkR[p], b)));
+        const uint32_t sum = block_sum_mod(acc, red);
+        if (threadIdx.x == 0) a.out[p] = sum;
+    }
+}
+
+// Merkle openings: one thread per (opening, level) copies the sibling digest; one thread per opening adds salt, value, flags
+__global__ void __launch_bounds__(256) merkle_open_kernel(const Digest* __restrict__ levels, uint64_t n, const uint32_t* __restrict__ values,
+                                                          const uint4* __restrict__ salts, const uint32_t* __restrict__ indices, uint32_t nidx,
+                                                          uint8_t* __restrict__ out) {
+    const uint32_t depth = merkle_depth(n);
+    const uint64_t rec = merkle_open_record_bytes(n);
+    const uint64_t total = (uint64_t)nidx * (depth + 1);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const uint32_t k = (uint32_t)(w / (depth + 1)), level = (uint32_t)(w % (depth + 1));
+        const uint64_t index = indices[k];
+        uint8_t* r = out + (uint64_t)k * rec;
+        if (level < depth) {
+            bool is_left;
+            const uint64_t row = merkle_sibling_row(n, index, level, is_left);
+            reinterpret_cast<Digest*>(r)[level] = levels[row];       // records are 8-byte aligned, digests are u32 words
+            r[(uint64_t)depth * 32u + 24u + level] = is_left ? 1 : 0;
+        } else {
+            uint32_t* tail = reinterpret_cast<uint32_t*>(r + (uint64_t)depth * 32u);
+            uint4 sv = make_uint4(0u, 0u, 0u, 0u);
+            if (salts) sv = salts[index];
+            tail[0] = sv.x; tail[1] = sv.y; tail[2] = sv.z; tail[3] = sv.w;
+            tail[4] = values[index];
+            tail[5] = 0u;
+        }
     }
 }
 
@@ -1239,7 +1393,8 @@ int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, ui
 }
 
 // ---- FRI fold ----
-static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s) {
+static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s,
+                        const uint8_t* d_salts = nullptr, uint8_t* d_leaves = nullptr) {
     if (m % 2) return TOYNI_E_ODD_LENGTH;
     if (m == 0) return TOYNI_OK;
     if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
@@ -1254,8 +1409,16 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
     const size_t work = (f.half & 3) ? f.half : f.half / 4;
-    if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) hipLaunchKernelGGL(fri_fold_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, f);
-    else hipLaunchKernelGGL(fri_fold_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, f);
+    const uint4* no_salts = nullptr;
+    Digest* no_leaves = nullptr;
+    if (d_leaves) {
+        hipLaunchKernelGGL((fri_fold_kernel<false, true>), dim3(grid_for(work)), dim3(256), 0, s, f, reinterpret_cast<const uint4*>(d_salts),
+                           reinterpret_cast<Digest*>(d_leaves));
+    } else if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) {
+        hipLaunchKernelGGL((fri_fold_kernel<true, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
+    } else {
+        hipLaunchKernelGGL((fri_fold_kernel<false, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1426,13 +1589,21 @@ size_t toyni_merkle_total_digests(size_t n) {
     return total;
 }
 
+// levels above the leaf hashes (already in d_levels[0 .. n))
+static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s);
+
 int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts, size_t n, uint8_t* d_levels, void* stream) {
     if (!d_values || !d_levels) return TOYNI_E_NULL;
     if (n == 0) return TOYNI_OK;
     if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15)) return TOYNI_E_RANGE;  // 16-byte accesses
     hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(merkle_leaf_kernel, dim3(grid_for(n)), dim3(256), 0, s, d_values, reinterpret_cast<const uint4*>(d_salts),
+                       reinterpret_cast<Digest*>(d_levels), n);
+    return enqueue_merkle_upper(d_levels, n, s);
+}
+
+static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s) {
     Digest* cur = reinterpret_cast<Digest*>(d_levels);
-    hipLaunchKernelGGL(merkle_leaf_kernel, dim3(grid_for(n)), dim3(256), 0, s, d_values, reinterpret_cast<const uint4*>(d_salts), cur, n);
     size_t m = n;
     while (m > MERKLE_TAIL) {
         const size_t up = (m + 1) / 2;
@@ -1465,6 +1636,131 @@ int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, s
     HIPCHK(hipMemcpyAsync(h_levels, st->buf[4], total * 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return TOYNI_OK;
+}
+
+// ---- fold + commit, pointwise prover steps (include/toyni_hip.h 3c) ----
+// src/fibonacci.rs:222-245, one protocol round on the device: fold layer k with beta_k, and commit the folded layer (leaf
+// hashes in the same sweep, then the node levels).  The NEXT beta depends on this commitment's root (the transcript absorbs it
+// before the next squeeze, :242-243), so rounds cannot be fused further: the caller reads the root (last 32 bytes of the levels),
+// derives beta and calls again.
+int toyni_fri_fold_commit_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0,
+                                 const uint8_t* d_salts, uint8_t* d_levels, void* stream) {
+    if (!c || !d_evals || !d_out || !d_levels) return TOYNI_E_NULL;
+    if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15)) return TOYNI_E_RANGE;
+    if (m < 2) return m % 2 ? TOYNI_E_ODD_LENGTH : TOYNI_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = enqueue_fold(c, d_evals, d_out, m, beta, x0, s, d_salts, d_levels);
+    if (rc) return rc;
+    return enqueue_merkle_upper(d_levels, m / 2, s);
+}
+
+static DomainArgs domain_args(toyni_ntt_ctx* c, unsigned log_m, uint32_t shift) {
+    DomainArgs d{};
+    d.lo = c->d_fwd + c->plan.dom_lo_off;
+    d.hi = c->d_fwd + c->plan.dom_hi_off;
+    d.lowbits = c->plan.dom_lowbits;
+    d.log_step = (uint32_t)(c->plan.log_n - (int)log_m);
+    d.shiftR = to_mont_host(shift);
+    return d;
+}
+
+int toyni_fib_quotient_device(toyni_ntt_ctx* c, const uint32_t* d_trace_lde, uint32_t* d_c_evals, uint32_t* d_q_evals, unsigned log_blowup,
+                              uint32_t shift, void* stream) {
+    if (!c || !d_trace_lde || !d_q_evals) return TOYNI_E_NULL;
+    const int log_N = c->plan.log_n;
+    if ((int)log_blowup > log_N || log_blowup > 10 || shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
+    const int log_n = log_N - (int)log_blowup;
+    if (log_n < 1) return TOYNI_E_RANGE;                                    // the AIR needs a trace of at least two rows
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    QuotientArgs a{};
+    a.trace = d_trace_lde;
+    a.c_out = d_c_evals;
+    a.q_out = d_q_evals;
+    a.dom = domain_args(c, (unsigned)log_N, shift);
+    a.log_N = (uint32_t)log_N;
+    a.log_blowup = log_blowup;
+    const uint64_t n = 1ull << log_n;
+    const uint32_t g = bb_root_of_unity_host((uint32_t)log_n);                // domain.group_gen(), src/fibonacci.rs:108
+    a.b1R = to_mont_host(bb_pow_host(g, n - 1));
+    a.b2R = to_mont_host(bb_pow_host(g, n - 2));
+    a.shift_nR = to_mont_host(bb_pow_host(shift, n));
+    a.wBR = to_mont_host(bb_pow_host(bb_root_of_unity_host((uint32_t)log_N), n));
+    // Z_H(x) = 0 on the coset only if shift^n is a B-th root of unity: then the quotient does not exist (the reference divides by zero)
+    {
+        uint32_t t = bb_pow_host(shift, n);
+        if (bb_pow_host(t, 1ull << log_blowup) == 1u) return TOYNI_E_ZERO_INVERSE;
+    }
+    const uint64_t items = (log_blowup >= 2 && log_N >= 2) ? (1ull << log_N) / 4 : (1ull << log_N);
+    hipLaunchKernelGGL(fib_quotient_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int toyni_fib_deep_device(toyni_ntt_ctx* c, const uint32_t* d_trace_lde, const uint32_t* d_q_evals, uint32_t* d_out, unsigned log_blowup,
+                          uint32_t shift, uint32_t z, const uint32_t ood[4], void* stream) {
+    if (!c || !d_trace_lde || !d_q_evals || !d_out || !ood) return TOYNI_E_NULL;
+    const int log_N = c->plan.log_n;
+    if ((int)log_blowup > log_N || shift == 0 || shift >= BB_P || z >= BB_P) return TOYNI_E_RANGE;
+    for (int k = 0; k < 4; ++k) if (ood[k] >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    DeepArgs a{};
+    a.trace = d_trace_lde;
+    a.quot = d_q_evals;
+    a.out = d_out;
+    a.dom = domain_args(c, (unsigned)log_N, shift);
+    a.log_N = (uint32_t)log_N;
+    a.log_blowup = log_blowup;
+    a.wNR = to_mont_host(bb_root_of_unity_host((uint32_t)log_N));
+    a.zR = to_mont_host(z);
+    a.t_z = ood[0]; a.t_gz = ood[1]; a.t_ggz = ood[2]; a.q_z = ood[3];
+    const uint64_t items = log_N >= 3 ? (1ull << log_N) / 8 : (1ull << log_N);
+    hipLaunchKernelGGL(fib_deep_kernel, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int toyni_poly_eval_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, size_t ncoeffs, const uint32_t* points, unsigned npoints, uint32_t* d_out,
+                           void* stream) {
+    if (!c || !points || !d_out || (!d_coeffs && ncoeffs)) return TOYNI_E_NULL;
+    if (npoints < 1 || npoints > (unsigned)POLY_MAX_POINTS) return TOYNI_E_RANGE;
+    for (unsigned p = 0; p < npoints; ++p) if (points[p] >= BB_P) return TOYNI_E_RANGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (ncoeffs == 0) return (int)hipMemsetAsync(d_out, 0, npoints * sizeof(uint32_t), s);  // the zero polynomial, polynomial.rs:135-137
+    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
+    PolyEvalArgs a{};
+    a.coeffs = d_coeffs;
+    a.ncoeffs = ncoeffs;
+    a.npoints = npoints;
+    a.nblocks = (uint32_t)((ncoeffs + POLY_CHUNK - 1) / POLY_CHUNK);
+    int rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, (size_t)a.nblocks * npoints, sizeof(uint32_t));
+    if (rc) return rc;
+    a.partial = sc.d_lde32;
+    a.out = d_out;
+    for (unsigned p = 0; p < npoints; ++p) {
+        a.zR[p] = to_mont_host(points[p]);
+        a.z16R[p] = to_mont_host(bb_pow_host(points[p], POLY_PER_THREAD));
+        a.zchunkR[p] = to_mont_host(bb_pow_host(points[p], POLY_CHUNK));
+    }
+    hipLaunchKernelGGL(poly_eval_partial_kernel, dim3(a.nblocks), dim3(POLY_THREADS), 0, s, a);
+    hipLaunchKernelGGL(poly_eval_final_kernel, dim3(1), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+size_t toyni_merkle_open_record_bytes(size_t n) { return n ? (size_t)merkle_open_record_bytes(n) : 0; }
+
+int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* d_values, const uint8_t* d_salts, const uint32_t* d_indices,
+                             size_t nidx, uint8_t* d_out, void* stream) {
+    if (!d_levels || !d_values || !d_indices || !d_out) return TOYNI_E_NULL;
+    if (n == 0 || nidx == 0) return TOYNI_OK;
+    if (n > 0xFFFFFFFFull || nidx > 0xFFFFFFFFull || ((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15) || ((uintptr_t)d_out & 7)) return TOYNI_E_RANGE;
+    const uint64_t work = (uint64_t)nidx * (merkle_depth(n) + 1);
+    hipLaunchKernelGGL(merkle_open_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const Digest*>(d_levels),
+                       (uint64_t)n, d_values, reinterpret_cast<const uint4*>(d_salts), d_indices, (uint32_t)nidx, d_out);
+    return (int)hipGetLastError();
 }
 
 // ---- plumbing ----

@@ -1,0 +1,58 @@
+"""Device-resident steps of the Fibonacci prover around the hot path (include/toyni_hip.h 3c): one FRI round with its
+commitment, constraint / quotient / DEEP evaluation on the LDE coset, polynomial evaluation at the out-of-domain points, and
+Merkle openings.  Mirrors the corresponding lines of `StarkProver::generate_proof` (src/fibonacci.rs:133-150,186-198,222-245,
+366-375) as calls on packed-u32 device pointers; no host arithmetic, no CPU path."""
+import numpy as np
+
+from ._lib import check, lib
+
+
+def fri_fold_commit_device(ctx, d_evals: int, d_out: int, m: int, beta: int, x0: int, d_salts: int, d_levels: int, stream: int = 0) -> None:
+    """fold a layer of m values and commit the folded layer (all tree levels to d_levels) in one call."""
+    check(lib.toyni_fri_fold_commit_device(ctx.handle, d_evals, d_out, m, beta, x0, d_salts or None, d_levels, stream or None),
+          "GPU fold + commit failed")
+
+
+def fib_quotient_device(ctx, d_trace_lde: int, d_c_evals: int, d_q_evals: int, log_blowup: int, shift: int, stream: int = 0) -> None:
+    check(lib.toyni_fib_quotient_device(ctx.handle, d_trace_lde, d_c_evals or None, d_q_evals, log_blowup, shift, stream or None),
+          "GPU constraint / quotient evaluation failed")
+
+
+def fib_deep_device(ctx, d_trace_lde: int, d_q_evals: int, d_out: int, log_blowup: int, shift: int, z: int, ood, stream: int = 0) -> None:
+    o = np.ascontiguousarray(ood, dtype=np.uint32)
+    assert o.size == 4
+    check(lib.toyni_fib_deep_device(ctx.handle, d_trace_lde, d_q_evals, d_out, log_blowup, shift, z, o.ctypes.data, stream or None),
+          "GPU DEEP evaluation failed")
+
+
+def poly_eval_device(ctx, d_coeffs: int, ncoeffs: int, points, d_out: int, stream: int = 0) -> None:
+    p = np.ascontiguousarray(points, dtype=np.uint32)
+    check(lib.toyni_poly_eval_device(ctx.handle, d_coeffs, ncoeffs, p.ctypes.data, p.size, d_out, stream or None), "GPU polynomial evaluation failed")
+
+
+def merkle_open_record_bytes(n: int) -> int:
+    return lib.toyni_merkle_open_record_bytes(n)
+
+
+def merkle_open_device(d_levels: int, n: int, d_values: int, d_salts: int, d_indices: int, nidx: int, d_out: int, stream: int = 0) -> None:
+    check(lib.toyni_merkle_open_device(d_levels, n, d_values, d_salts or None, d_indices, nidx, d_out, stream or None), "GPU Merkle opening failed")
+
+
+def parse_openings(raw: np.ndarray, n: int, indices, salted: bool):
+    """Records of toyni_merkle_open_device -> the fields of MerkleOpening (src/fibonacci.rs:366-375)."""
+    depth = 0
+    m = n
+    while m > 1:
+        m = (m + 1) // 2
+        depth += 1
+    rec = merkle_open_record_bytes(n)
+    raw = np.asarray(raw, dtype=np.uint8).reshape(len(indices), rec)
+    out = []
+    for k, index in enumerate(indices):
+        r = raw[k]
+        path = [r[32 * l:32 * (l + 1)].tobytes() for l in range(depth)]
+        salt = r[32 * depth:32 * depth + 16].tobytes() if salted else b""
+        value = int.from_bytes(r[32 * depth + 16:32 * depth + 24].tobytes(), "little")
+        position = [bool(b) for b in r[32 * depth + 24:32 * depth + 24 + depth]]
+        out.append({"index": int(index), "value": value, "path": path, "position": position, "salt": salt})
+    return out
