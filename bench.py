@@ -36,7 +36,6 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip single-transform / fold / host-path side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--microbench", action="store_true", help="also print integer-multiply issue rates (stderr)")
     ap.add_argument("--chunks", type=int, default=1, help="slab workload: issue the exchange in this many asynchronous pieces")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the pass launches of the timed region with HIP events (A/B check of their cost)")
@@ -189,6 +188,52 @@ def probe_ranks(args):
         dist.destroy_process_group()
 
 
+class ToolsLib:
+    """libtoyni_hip_tools.so (the measurement build of the same source, include/toyni_hip_tools.h): launch-timing hooks.  The
+    timed region that produces `value` runs on the shipped libtoyni_hip.so; the roofline object's kernel durations come from
+    an identical region run through this build, with every pass launch bracketed by HIP events on the launch stream."""
+
+    def __init__(self, path):
+        import ctypes
+        self.ct = ctypes
+        self.lib = ctypes.CDLL(path)
+        vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        sig = {"toyni_ntt_ctx_create": (ci, [ctypes.c_uint32, ci, ctypes.POINTER(vp)]), "toyni_ntt_ctx_destroy": (ci, [vp]),
+               "toyni_ntt_ctx_passes": (ci, [vp]), "toyni_ntt_device": (ci, [vp, vp, vp, sz, ci, vp]),
+               "toyni_ntt_ctx_timing": (ci, [vp, ci]), "toyni_ntt_ctx_timing_read": (ci, [vp, vp, vp])}
+        for name, (res, args) in sig.items():
+            f = getattr(self.lib, name)
+            f.restype, f.argtypes = res, args
+
+    def context(self, n, device):
+        h = self.ct.c_void_p()
+        rc = self.lib.toyni_ntt_ctx_create(n, device, self.ct.byref(h))
+        assert rc == 0, f"tools context: status {rc}"
+        return h
+
+    def run(self, h, ptr, batch, inverse, stream):
+        rc = self.lib.toyni_ntt_device(h, ptr, ptr, batch, int(inverse), stream or None)
+        assert rc == 0, f"tools transform: status {rc}"
+
+    def timed_region(self, h, fn):
+        """Runs fn() with launch timing on; returns {'forward': [ms per pass], 'inverse': [...], 'launches': {...}}."""
+        assert self.lib.toyni_ntt_ctx_timing(h, 1) == 0
+        fn()
+        ms = (self.ct.c_float * 6)()
+        cnt = (self.ct.c_uint32 * 6)()
+        assert self.lib.toyni_ntt_ctx_timing_read(h, ms, cnt) == 0
+        assert self.lib.toyni_ntt_ctx_timing(h, 0) == 0
+        npass = self.lib.toyni_ntt_ctx_passes(h)
+        out = {"launches": {}}
+        for d, name in enumerate(("forward", "inverse")):
+            out[name] = [ms[3 * d + p] / cnt[3 * d + p] if cnt[3 * d + p] else None for p in range(npass)]
+            out["launches"][name] = [int(cnt[3 * d + p]) for p in range(npass)]
+        return out
+
+    def destroy(self, h):
+        self.lib.toyni_ntt_ctx_destroy(h)
+
+
 def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
     """HBM traffic and VALU instruction counts cannot be collected inside this process (rocprofv3 --pmc runs the command from
     outside): they are the COMMITTED rocprofv3 measurements of the same command (tools/collect_profiles.sh -> profiles/
@@ -252,6 +297,7 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build_hip()
+        entry.build_tools()
     if distributed:
         dist.barrier()
     import toyni_amd
@@ -290,11 +336,6 @@ def main():
         step()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # every pass launch of the timed region is bracketed by HIP events on the launch stream (library side,
-    # toyni_ntt_ctx_timing): the roofline object below prices exactly the launches `value` was measured on
-    kernel_events = rank == 0 and not args.no_kernel_events
-    if kernel_events:
-        ctx.timing(True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
@@ -303,10 +344,25 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     gpu_s = ev0.elapsed_time(ev1) / 1e3
-    region = None
-    if kernel_events:
-        region = ctx.read_timing()
-        ctx.timing(False)
+    # Kernel durations for the roofline object: the SAME region (same data, same steps) once more through the measurement
+    # build of the same source (libtoyni_hip_tools.so), where every pass launch is bracketed by HIP events on the launch stream.
+    region, tools_ms_per_step = None, None
+    if rank == 0 and not args.no_kernel_events:
+        tl = ToolsLib(entry.build_tools())
+        th = tl.context(n, dev.index)
+
+        def tools_steps():
+            for _ in range(args.steps):
+                tl.run(th, ptr, batch, False, stream)
+                tl.run(th, ptr, batch, True, stream)
+
+        tl.run(th, ptr, batch, False, stream)     # warm: tables, intermediate buffer
+        tl.run(th, ptr, batch, True, stream)
+        torch.cuda.synchronize()
+        t0t = time.perf_counter()
+        region = tl.timed_region(th, tools_steps)  # reading the events synchronises
+        tools_ms_per_step = (time.perf_counter() - t0t) / args.steps * 1e3
+        tl.destroy(th)
     # forward + inverse leaves the batch unchanged: an end-to-end check of the timed region over EVERY transform (a skipped
     # or duplicated tile anywhere shows up here), plus -- a round trip is the identity for many wrong transforms too -- one
     # forward transform (the last of the batch) against the oracle, outside the timed region
@@ -346,14 +402,15 @@ def main():
 
     # ---- roofline of the dominant kernel: per-pass launch durations, HIP events on the launch stream ----
     if rank == 0:
+        npass = ctx.passes
         if region is not None:
             fwd_ms, inv_ms = region["forward"], region["inverse"]
-            timing_src = f"HIP events around each of the {sum(region['launches']['forward']) + sum(region['launches']['inverse'])} pass launches of the timed region"
-        else:   # --no-kernel-events: the same kernels re-launched after the timed region
-            fwd_ms = ctx.profile_passes(ptr, batch, False, reps=10, stream=stream)
-            inv_ms = ctx.profile_passes(ptr, batch, True, reps=10, stream=stream)
-            timing_src = "HIP events, 10 back-to-back launches per pass after the timed region"
-        npass = ctx.passes
+            timing_src = (f"HIP events around each of the {sum(region['launches']['forward']) + sum(region['launches']['inverse'])} pass launches of "
+                          f"{args.steps} steps of the same workload, run right after the timed region through the measurement build "
+                          f"libtoyni_hip_tools.so (same source, -DTOYNI_TOOLS; {tools_ms_per_step:.3f} ms per step there)")
+        else:   # --no-kernel-events: no per-kernel durations; the whole transform's share of the step instead
+            fwd_ms = inv_ms = [wall_max / args.steps * 1e3 / (2 * npass)] * npass
+            timing_src = "no kernel events requested: ms_per_step / launches per step"
         dom = max(range(npass), key=lambda p: fwd_ms[p] + inv_ms[p])
         # The forward and the inverse launch of pass `dom` are the SAME kernel symbol (rocprofv3 averages them together),
         # so the kernel's average launch duration is taken over both directions.
@@ -462,12 +519,18 @@ def main():
         extras["batched_n2^24"] = {"batch": b24, "ms_per_fwd_inv": t24 * 1e3, "elements_per_s": 2 * b24 * n24 / t24,
                                    "passes_per_transform": c24.passes, "note": "same step as `value` at n = 2^24"}
         # the same roofline object for this size: per-pass launch durations from HIP events around the launches of 5 more steps
-        c24.timing(True)
-        for _ in range(5):
-            fb24()
-        torch.cuda.synchronize()
-        r24 = c24.read_timing()
-        c24.timing(False)
+        tl24 = ToolsLib(entry.build_tools())
+        th24 = tl24.context(n24, dev.index)
+        tl24.run(th24, p24, b24, False, stream)
+        tl24.run(th24, p24, b24, True, stream)
+
+        def steps24():
+            for _ in range(5):
+                tl24.run(th24, p24, b24, False, stream)
+                tl24.run(th24, p24, b24, True, stream)
+
+        r24 = tl24.timed_region(th24, steps24)
+        tl24.destroy(th24)
         f24, i24 = r24["forward"], r24["inverse"]
         np24 = c24.passes
         d24 = max(range(np24), key=lambda p: f24[p] + i24[p])
@@ -615,16 +678,6 @@ def main():
         t_m = time_dev(lambda: toyni_amd.merkle_commit_device(q1.data_ptr(), salts.data_ptr(), nl, lv.data_ptr(), stream=stream), 20)
         extras["merkle_commit_2^21_salted"] = {"us": t_m * 1e6, "note": "SHA-256 leaves + 21 node levels, device-resident, 22 launches"}
         out["extras"] = extras
-
-    if rank == 0 and args.microbench:
-        import ctypes
-        names = ["mont_mul", "barrett64", "add+sub", "mul_lo_u32", "mul_hi_u32", "mad_u64_u32"]
-        for which, nm in enumerate(names):
-            ms, sink = ctypes.c_float(0), ctypes.c_uint32(0)
-            iters, blocks = 4096, 256 * 8
-            toyni_amd._lib.check(toyni_amd._lib.lib.toyni_microbench(which, iters, blocks, ctypes.byref(ms), ctypes.byref(sink)), "microbench")
-            ops = iters * 8.0 * blocks * 256
-            print(f"[microbench] {nm:12s} {ops / (ms.value * 1e-3) / 1e12:8.3f} Tops/s  ({ms.value:.3f} ms)", file=sys.stderr)
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.log_n, args.cpu_seconds)

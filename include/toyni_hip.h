@@ -260,24 +260,6 @@ int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSy
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);
 
-/* Per-pass kernel timing for bench.py's roofline object: launches pass p of `batch` transforms `reps` times
- * between HIP events on `stream` (pass 0 reads d_data, later passes the context's work buffer; values stay
- * canonical but d_data's contents are overwritten).  ms_per_pass[p] = average launch duration in ms for
- * p < toyni_ntt_ctx_passes(ctx).  Blocking. */
-int toyni_ntt_profile_passes(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream);
-
-/* Launch durations of the pass kernels INSIDE a workload: while enabled, every pass launch this context enqueues
- * (toyni_ntt_device and friends) is bracketed by a pair of HIP events on the launch stream.  _read waits for the
- * recorded events, adds the durations into ms_sum[direction * 3 + pass] / launches[direction * 3 + pass]
- * (direction 0 = forward, 1 = inverse; both arrays hold 6 entries, zero-filled first) and drops the records.
- * bench.py brackets its timed region with enable / read, so the roofline object prices the launches that were timed. */
-int toyni_ntt_ctx_timing(toyni_ntt_ctx* ctx, int enable);
-int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* ctx, float* ms_sum, uint32_t* launches);
-
-/* Instruction-throughput probe used by bench.py --microbench (not part of the data path):
- * which = 0 mont_mul, 1 barrett64, 2 add/sub, 3 mul_lo, 4 mul_hi, 5 mad_u64_u32.  Returns elapsed ms. */
-int toyni_microbench(int which, int iters, int blocks, float* ms_out, uint32_t* sink_out);
-
 #ifdef __cplusplus
 }
 #endif

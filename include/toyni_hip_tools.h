@@ -1,0 +1,33 @@
+/*
+ * toyni_hip_tools.h -- measurement hooks of the MEASUREMENT BUILD libtoyni_hip_tools.so (the same translation unit as
+ * libtoyni_hip.so compiled with -DTOYNI_TOOLS).  They are NOT part of the shipped library or of the drop-in boundary
+ * (include/toyni_hip.h): bench.py uses them to price the pass kernels with HIP events on the launch stream (roofline object).
+ * The instruction-rate probe is its own program, tools/microbench.hip.
+ */
+#ifndef TOYNI_HIP_TOOLS_H
+#define TOYNI_HIP_TOOLS_H
+
+#include "toyni_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-pass kernel timing for bench.py's roofline object: launches pass p of `batch` transforms `reps` times
+ * between HIP events on `stream` (pass 0 reads d_data, later passes the context's work buffer; values stay
+ * canonical but d_data's contents are overwritten).  ms_per_pass[p] = average launch duration in ms for
+ * p < toyni_ntt_ctx_passes(ctx).  Blocking. */
+int toyni_ntt_profile_passes(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream);
+
+/* Launch durations of the pass kernels INSIDE a workload: while enabled, every pass launch this context enqueues
+ * (toyni_ntt_device and friends) is bracketed by a pair of HIP events on the launch stream.  _read waits for the
+ * recorded events, adds the durations into ms_sum[direction * 3 + pass] / launches[direction * 3 + pass]
+ * (direction 0 = forward, 1 = inverse; both arrays hold 6 entries, zero-filled first) and drops the records.
+ * bench.py brackets its timed region with enable / read, so the roofline object prices the launches that were timed. */
+int toyni_ntt_ctx_timing(toyni_ntt_ctx* ctx, int enable);
+int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* ctx, float* ms_sum, uint32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOYNI_HIP_TOOLS_H */

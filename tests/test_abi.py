@@ -33,6 +33,22 @@ def test_header_symbols_all_exported(lib):
     assert sorted(lib.SIGNATURES) == declared
 
 
+def test_measurement_hooks_live_in_the_tools_build_only(lib):
+    """include/toyni_hip_tools.h is exported by libtoyni_hip_tools.so (the same source with -DTOYNI_TOOLS) and by nothing shipped."""
+    import ctypes
+    import __graft_entry__ as entry
+    src = open(os.path.join(ROOT, "include", "toyni_hip_tools.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(toyni_[a-z0-9_]*)\s*\(", src)))
+    assert declared == sorted(lib.TOOLS_SIGNATURES)
+    tools = ctypes.CDLL(entry.build_tools())
+    for name in declared:
+        assert hasattr(tools, name) and not hasattr(lib.lib, name), name
+    for name in lib.SIGNATURES:                      # the measurement build is a superset of the shipped ABI
+        assert hasattr(tools, name), name
+    assert not hasattr(lib.lib, "toyni_microbench") and not hasattr(tools, "toyni_microbench")   # its own program: tools/microbench.hip
+
+
 def test_reference_abi_names_present(lib):
     # the nine symbols src/ntt.rs:95-110 binds (cudaGetDeviceCount is replaced by toyni_device_count)
     for name in ["ntt_ctx_create", "ntt_ctx_destroy", "ntt_run_inplace", "intt_run_inplace", "cuda_malloc", "cuda_free",

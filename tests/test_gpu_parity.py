@@ -622,13 +622,29 @@ def test_slab_entry_points_reject_bad_shapes(ta):
     buf.free()
 
 
+def _run_on_measurement_build(code, extra_env=None, timeout=300):
+    """Runs `code` in a child interpreter whose toyni_amd is bound to libtoyni_hip_tools.so (the measurement build of the same
+    source, include/toyni_hip_tools.h): the launch-timing hooks live there, not in the shipped library."""
+    import os
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pp = os.pathsep.join([root, os.path.join(root, "tests")])
+    env = dict(os.environ, PYTHONPATH=pp, TOYNI_LIB_OVERRIDE=entry.build_tools(), **(extra_env or {}))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_shipped_library_has_no_measurement_hooks(ta):
+    assert not ta._lib.HAS_TOOLS and not hasattr(ta._lib.lib, "toyni_ntt_profile_passes")
+    with pytest.raises(RuntimeError, match="measurement build"):
+        ta.ntt.get_or_create_ctx(1 << 12).timing(True)
+
+
 def test_both_executors_of_the_single_sweep_sizes(ta):
     # n = 2^11 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
     # batches of 2^11 .. 2^13 only).  Force each one for every size, small ragged batches, in child processes (the knobs are
     # read once per process); which executor ran is read off the launch records (1 launch per transform vs 2).
-    import os
-    import subprocess
-    import sys
     code = (
         "import os, numpy as np, oracle, toyni_amd\n"
         "from test_gpu_parity import DevBuf\n"
@@ -652,39 +668,40 @@ def test_both_executors_of_the_single_sweep_sizes(ta):
         "        assert (f[b * n:(b + 1) * n] == oracle.ntt(row)).all()\n"
         "        assert (i[b * n:(b + 1) * n] == oracle.domain_ifft(row, 7)).all()\n"
         "print('EXECUTOR OK')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pp = os.pathsep.join([root, os.path.join(root, "tests")])
     modes = [("two-pass", {"TOYNI_NO_LDS_KERNEL": "1", "TOYNI_TEST_LAUNCHES": "2"}),
              # the non-temporal kernel variants (normally chosen for footprints >= 512 MiB) forced on small data
              ("two-pass, non-temporal", {"TOYNI_NO_LDS_KERNEL": "1", "TOYNI_NT_MIN_BYTES": "0", "TOYNI_TEST_LAUNCHES": "2"}),
              ("sweep, 4 workgroups per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_TEST_LAUNCHES": "1"}),
              ("sweep, 1 workgroup per CU", {"TOYNI_LDS_MAX_LOG": "15", "TOYNI_LDS_MIN_ELEMS": "0", "TOYNI_LDS_ROWS": "5", "TOYNI_TEST_LAUNCHES": "1"})]
     for mode, extra in modes:
-        env = dict(os.environ, PYTHONPATH=pp, **extra)
-        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        res = _run_on_measurement_build(code, extra)
         assert res.returncode == 0 and "EXECUTOR OK" in res.stdout, mode + ": " + res.stdout[-1000:] + res.stderr[-3000:]
 
 
 def test_large_batches_of_mid_sizes_take_the_single_sweep_kernel(ta):
-    # the default policy: >= 2^25 elements of n = 2^11 .. 2^13 per call -> one launch; checked against the oracle on sampled rows
-    n, batch = 1 << 12, 1 << 13
-    rng = np.random.default_rng(12)
-    x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
-    ctx = ta.NttContext(n)
-    buf = DevBuf(ta, x.nbytes)
-    buf.upload(x)
-    ctx.timing(True)
-    ctx.run_device(buf.ptr, buf.ptr, batch, False)
-    assert ctx.read_timing()["launches"]["forward"] == [1, 0]
-    ctx.timing(False)
-    got = buf.download(np.uint32, x.size)
-    for b in (0, 1, 7, 4095, 4096, batch - 1):
-        assert (got[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n].astype(np.uint64))).all(), b
-    ctx.run_device(buf.ptr, buf.ptr, batch, True)
-    ctx.synchronize()
-    assert (buf.download(np.uint32, x.size) == x).all()
-    buf.free()
-    ctx.destroy()
+    # the default policy: >= 2^25 elements of n = 2^11 .. 2^13 per call -> one launch (counted on the measurement build);
+    # checked against the oracle on sampled rows
+    code = (
+        "import numpy as np, oracle, toyni_amd\n"
+        "from test_gpu_parity import DevBuf\n"
+        "n, batch = 1 << 12, 1 << 13\n"
+        "x = np.random.default_rng(12).integers(0, oracle.P, size=n * batch, dtype=np.uint32)\n"
+        "ctx = toyni_amd.NttContext(n)\n"
+        "buf = DevBuf(toyni_amd, x.nbytes)\n"
+        "buf.upload(x)\n"
+        "ctx.timing(True)\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, False)\n"
+        "assert ctx.read_timing()['launches']['forward'] == [1, 0]\n"
+        "ctx.timing(False)\n"
+        "got = buf.download(np.uint32, x.size)\n"
+        "for b in (0, 1, 7, 4095, 4096, batch - 1):\n"
+        "    assert (got[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n].astype(np.uint64))).all(), b\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, True)\n"
+        "ctx.synchronize()\n"
+        "assert (buf.download(np.uint32, x.size) == x).all()\n"
+        "print('SWEEP OK')\n")
+    res = _run_on_measurement_build(code)
+    assert res.returncode == 0 and "SWEEP OK" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
 # ---------------------------------------------------------------- low-degree extension (src/fibonacci.rs:101-103)
@@ -785,26 +802,33 @@ def test_domain_elements_match_reference_chain(ta, log_ctx, log_m, shift):
 
 
 def test_in_workload_launch_timing(ta):
-    # toyni_ntt_ctx_timing: every pass launch between enable and read is bracketed by events; results are untouched
-    n, batch = 1 << 16, 8
-    x = oracle.splitmix(n * batch, 4242).astype(np.uint32)
-    ctx = ta.NttContext(n)
-    buf = DevBuf(ta, x.nbytes)
-    buf.upload(x)
-    ctx.timing(True)
-    ctx.run_device(buf.ptr, buf.ptr, batch, False)
-    ctx.run_device(buf.ptr, buf.ptr, batch, True)
-    ctx.run_device(buf.ptr, buf.ptr, batch, False)
-    t = ctx.read_timing()
-    ctx.timing(False)
-    assert t["launches"] == {"forward": [2, 2], "inverse": [1, 1]}
-    assert all(v is not None and 0.0 < v < 50.0 for v in t["forward"] + t["inverse"])
-    ctx.run_device(buf.ptr, buf.ptr, batch, True)                      # not recorded any more
-    ctx.synchronize()
-    assert ctx.read_timing()["launches"] == {"forward": [0, 0], "inverse": [0, 0]}
-    assert (buf.download(np.uint32, n * batch) == x).all()
-    buf.free()
-    ctx.destroy()
+    # measurement build, toyni_ntt_ctx_timing: every pass launch between enable and read is bracketed by events; results are
+    # untouched; a lone 2^16 transform takes the three-step latency shapes (still two launches)
+    code = (
+        "import numpy as np, oracle, toyni_amd\n"
+        "from test_gpu_parity import DevBuf\n"
+        "n, batch = 1 << 16, 8\n"
+        "x = oracle.splitmix(n * batch, 4242).astype(np.uint32)\n"
+        "ctx = toyni_amd.NttContext(n)\n"
+        "buf = DevBuf(toyni_amd, x.nbytes)\n"
+        "buf.upload(x)\n"
+        "ctx.timing(True)\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, False)\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, True)\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, False)\n"
+        "t = ctx.read_timing()\n"
+        "ctx.timing(False)\n"
+        "assert t['launches'] == {'forward': [2, 2], 'inverse': [1, 1]}, t\n"
+        "assert all(v is not None and 0.0 < v < 50.0 for v in t['forward'] + t['inverse'])\n"
+        "ctx.run_device(buf.ptr, buf.ptr, batch, True)\n"
+        "ctx.synchronize()\n"
+        "assert ctx.read_timing()['launches'] == {'forward': [0, 0], 'inverse': [0, 0]}\n"
+        "assert (buf.download(np.uint32, n * batch) == x).all()\n"
+        "p = ctx.profile_passes(buf.ptr, batch, False, reps=3)\n"
+        "assert len(p) == 2 and all(0.0 < v < 50.0 for v in p)\n"
+        "print('TIMING OK')\n")
+    res = _run_on_measurement_build(code)
+    assert res.returncode == 0 and "TIMING OK" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
 
 
 # ---------------------------------------------------------------- Ext-valued fold (src/math/fri.rs:7-25)

@@ -65,8 +65,6 @@ SIGNATURES = {
     "toyni_ntt_ctx_device": (c_int, [c_void_p]),
     "toyni_ntt_ctx_passes": (c_int, [c_void_p]),
     "toyni_ntt_ctx_set_chunk": (c_int, [c_void_p, c_size]),
-    "toyni_ntt_ctx_timing": (c_int, [c_void_p, c_int]),
-    "toyni_ntt_ctx_timing_read": (c_int, [c_void_p, c_void_p, c_void_p]),
     "toyni_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_int]),
     "toyni_ntt_host_multi_gpu": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_size, c_int]),
     "toyni_ntt_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_int, c_void_p]),
@@ -114,14 +112,25 @@ SIGNATURES = {
     "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
     "toyni_ntt_ctx_trim": (c_int, [c_void_p]),
     "toyni_set_device": (c_int, [c_int]),
+}
+
+# include/toyni_hip_tools.h: present only in the measurement build libtoyni_hip_tools.so (TOYNI_LIB_OVERRIDE points at it)
+TOOLS_SIGNATURES = {
+    "toyni_ntt_ctx_timing": (c_int, [c_void_p, c_int]),
+    "toyni_ntt_ctx_timing_read": (c_int, [c_void_p, c_void_p, c_void_p]),
     "toyni_ntt_profile_passes": (c_int, [c_void_p, c_void_p, c_size, c_int, c_int, ctypes.POINTER(ctypes.c_float), c_void_p]),
-    "toyni_microbench": (c_int, [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_u32)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
     _f = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
     _f.restype = _res
     _f.argtypes = _args
+HAS_TOOLS = hasattr(lib, "toyni_ntt_ctx_timing")
+if HAS_TOOLS:
+    for _name, (_res, _args) in TOOLS_SIGNATURES.items():
+        _f = getattr(lib, _name)
+        _f.restype = _res
+        _f.argtypes = _args
 
 
 def error_string(status: int) -> str:

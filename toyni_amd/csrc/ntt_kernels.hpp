@@ -291,14 +291,14 @@ struct Pass {
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
                 st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
-                if (b + 1 < NB) { tw = mont_mul(tw, twd.g); TOYNI_PIN(tw); }
+                if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else if (a.cs_mode == 2u) {  // inverse coset transform: * s^k, k = k0 + b * (register step), running product
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
                 st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
-                if (b + 1 < NB) { tw = mont_mul(tw, twd.g); TOYNI_PIN(tw); }
+                if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else {
             const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
@@ -448,7 +448,7 @@ struct Pass {
 #pragma unroll
             for (uint32_t i = 0; i < NZ; ++i) {
                 x[i] = mont_mul(x[i], tw);
-                if (i + 1 < NZ) { tw = mont_mul(tw, a.cs_g); TOYNI_PIN(tw); }
+                if (i + 1 < NZ) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
             }
         }
     }
@@ -672,7 +672,7 @@ struct Pass3 {
 #pragma unroll
             for (uint32_t i = 0; i < NZ; ++i) {
                 x[i] = mont_mul(x[i], tw0);
-                if (i + 1 < NZ) { tw0 = mont_mul(tw0, a.cs_g); TOYNI_PIN(tw0); }
+                if (i + 1 < NZ) { tw0 = mont_mul_lazy(tw0, a.cs_g); TOYNI_PIN(tw0); }
             }
         }
         const uint32_t* tw1 = tw + ((1u << LLO) - E3);   // the table from stage LLO on
@@ -767,7 +767,7 @@ struct Pass3 {
                 uint32_t v = x[cx_bitrev(b, LE3)];
                 if (twiddled) {
                     v = mont_mul(v, tw0);
-                    if (b + 1 < E3) { tw0 = mont_mul(tw0, seeds.g); TOYNI_PIN(tw0); }
+                    if (b + 1 < E3) { tw0 = mont_mul_lazy(tw0, seeds.g); TOYNI_PIN(tw0); }
                 }
                 st32<NT_>(reinterpret_cast<uint32_t*>(obase + (uint64_t)b * step), off0, v);
             }

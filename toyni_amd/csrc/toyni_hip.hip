@@ -11,6 +11,9 @@
 #include <thread>
 #include <vector>
 
+#ifdef TOYNI_TOOLS
+#include "toyni_hip_tools.h"
+#endif
 #include "toyni_hip.h"  // include/toyni_hip.h: -I include here; next to this file in a crate's hip/ directory
 #include "ntt_plan.hpp"
 #include "merkle_kernels.hpp"
@@ -275,7 +278,9 @@ template <bool NT, bool COMMIT = false>
 __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f, const uint4* __restrict__ salts = nullptr, Digest* __restrict__ leaves = nullptr) {
     const uint64_t half = f.half;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    if ((half & 3) == 0) {
+    // COMMIT: one output and one leaf hash per thread (a SHA-256 compression is ~1 500 instructions against ~20 for the fold:
+    // the sweep is hash-bound, so it is kept as wide as the separate leaf kernel)
+    if (!COMMIT && (half & 3) == 0) {
         const uint4* ea = reinterpret_cast<const uint4*>(f.evals);
         const uint4* eb = reinterpret_cast<const uint4*>(f.evals + half);
         uint4* o = reinterpret_cast<uint4*>(f.out);
@@ -300,19 +305,6 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f, const u
                 __builtin_nontemporal_store(vr, reinterpret_cast<u32x4*>(o + q));
             } else {
                 o[q] = r;
-            }
-            if constexpr (COMMIT) {
-                const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (salts) {
-                        const uint4 sv = salts[4 * q + j];
-                        const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
-                        leaves[4 * q + j] = merkle_leaf(rv[j], sw);
-                    } else {
-                        leaves[4 * q + j] = merkle_leaf(rv[j], nullptr);
-                    }
-                }
             }
         }
     } else {
@@ -605,33 +597,6 @@ __global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restri
     }
 }
 
-// instruction-throughput probe (8 independent chains per lane)
-template <int WHICH>
-__global__ void __launch_bounds__(256) microbench_kernel(uint32_t seed, int iters, uint32_t* sink) {
-    uint32_t x[8];
-    uint64_t y[8];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { x[j] = (seed + t * 8u + j) % BB_P; y[j] = x[j]; }
-    const uint32_t w = (seed * 2654435761u) % BB_P;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (WHICH == 0) x[j] = mont_mul(x[j], w);
-            else if (WHICH == 1) x[j] = bb_mul_barrett64(x[j], w);
-            else if (WHICH == 2) x[j] = bb_sub(bb_add(x[j], w), seed);
-            else if (WHICH == 3) x[j] = x[j] * w + 1u;
-            else if (WHICH == 4) x[j] = __umulhi(x[j], w) + seed;
-            else y[j] = (uint64_t)(uint32_t)y[j] * w + y[j];
-        }
-    }
-    uint32_t acc = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc ^= x[j] ^ (uint32_t)y[j] ^ (uint32_t)(y[j] >> 32);
-    if (acc == 0xFFFFFFFFu) sink[0] = acc;  // practically never; keeps the chains live
-    if (t == 0) sink[1] = acc;
-}
-
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -672,9 +637,11 @@ struct toyni_ntt_ctx {
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
+#ifdef TOYNI_TOOLS                  // measurement build only (libtoyni_hip_tools.so, include/toyni_hip_tools.h)
     struct TimingRec { hipEvent_t e0, e1; int dir, pass; };
     bool timing = false;             // toyni_ntt_ctx_timing: bracket every pass launch with events
     std::vector<TimingRec> timing_recs;
+#endif
     uint32_t* d_ones = nullptr;      // Montgomery ones: the twiddle-free closing pass of a multi-device inverse (slab_pass)
     std::mutex mu;
 };
@@ -824,6 +791,32 @@ unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+// Measurement build (-DTOYNI_TOOLS, libtoyni_hip_tools.so): every pass launch of a context whose timing switch is on is
+// bracketed by a pair of HIP events on the launch stream.  The shipped library compiles these hooks to nothing.
+#ifdef TOYNI_TOOLS
+struct PassTimer {
+    toyni_ntt_ctx* c;
+    hipStream_t s;
+    toyni_ntt_ctx::TimingRec rec;
+    bool on;
+    PassTimer(toyni_ntt_ctx* c_, hipStream_t s_, int dir, int pass) : c(c_), s(s_), rec{nullptr, nullptr, dir, pass}, on(false) {
+        if (!c->timing) return;
+        if (hipEventCreate(&rec.e0) != hipSuccess) return;
+        if (hipEventCreate(&rec.e1) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
+        (void)hipEventRecord(rec.e0, s);
+        on = true;
+    }
+    ~PassTimer() {
+        if (!on) return;
+        (void)hipEventRecord(rec.e1, s);
+        c->timing_recs.push_back(rec);
+    }
+};
+#define TOYNI_PASS_TIMER(c, s, dir, pass) PassTimer _pass_timer((c), (s), (dir), (pass))
+#else
+#define TOYNI_PASS_TIMER(c, s, dir, pass) ((void)0)
+#endif
+
 int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 
 // Enqueue the passes of `batch` transforms on stream s (d_in == d_out allowed).  shift != 1: the coset scaling of
@@ -855,20 +848,11 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         const bool ok = lds_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch,
                                       [&](auto pass, const LdsArgs& g, uint64_t ntiles) {
                                           using L = decltype(pass);
-                                          toyni_ntt_ctx::TimingRec rec{nullptr, nullptr, inverse ? 1 : 0, 0};
-                                          if (c->timing) {
-                                              if ((err = hipEventCreate(&rec.e0)) != hipSuccess) return;
-                                              if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
-                                              (void)hipEventRecord(rec.e0, s);
-                                          }
+                                          TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, 0);
                                           uint64_t grid = (uint64_t)c->num_cus * L::WG_PER_CU;  // as many workgroups as the LDS of a CU holds
                                           if (grid > ntiles) grid = ntiles;
                                           hipLaunchKernelGGL((ntt_lds_kernel<L>), dim3((unsigned)grid), dim3(L::T), 0, s, g, (uint32_t)ntiles);
                                           err = hipGetLastError();
-                                          if (c->timing) {
-                                              (void)hipEventRecord(rec.e1, s);
-                                              c->timing_recs.push_back(rec);
-                                          }
                                       }, cs, lds_log_rows());
         if (!ok) return TOYNI_E_INVALID_SIZE;
         return (int)err;
@@ -896,18 +880,9 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
                                     constexpr int LZ = decltype(lzc)::value;
                                     const int p = pass_index++;
                                     if (err != hipSuccess) return;
-                                    toyni_ntt_ctx::TimingRec rec{nullptr, nullptr, inverse ? 1 : 0, p};
-                                    if (c->timing) {
-                                        if ((err = hipEventCreate(&rec.e0)) != hipSuccess) return;
-                                        if ((err = hipEventCreate(&rec.e1)) != hipSuccess) { (void)hipEventDestroy(rec.e0); return; }
-                                        (void)hipEventRecord(rec.e0, s);
-                                    }
+                                    TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, p);
                                     launch_pass<P, LZ>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
                                     err = hipGetLastError();
-                                    if (c->timing) {
-                                        (void)hipEventRecord(rec.e1, s);
-                                        c->timing_recs.push_back(rec);
-                                    }
                                 }, cs, lde_log, nt);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
@@ -1047,7 +1022,9 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         for (auto& r : c->retired) (void)hipFree(r.ptr);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
         (void)hipFree(c->d_ones);
+#ifdef TOYNI_TOOLS
         for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+#endif
     }
     delete c;
     return TOYNI_OK;
@@ -1057,6 +1034,7 @@ uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
 int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
 
+#ifdef TOYNI_TOOLS  // include/toyni_hip_tools.h
 int toyni_ntt_ctx_timing(toyni_ntt_ctx* c, int enable) {
     if (!c) return TOYNI_E_NULL;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1087,6 +1065,8 @@ int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* c, float* ms_sum, uint32_t* launche
     c->timing_recs.clear();
     return (int)err;
 }
+
+#endif  // TOYNI_TOOLS
 
 int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* c, size_t chunk_elems) {
     if (!c) return TOYNI_E_NULL;
@@ -1408,7 +1388,7 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     f.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
-    const size_t work = (f.half & 3) ? f.half : f.half / 4;
+    const size_t work = (d_leaves || (f.half & 3)) ? f.half : f.half / 4;
     const uint4* no_salts = nullptr;
     Digest* no_leaves = nullptr;
     if (d_leaves) {
@@ -1805,6 +1785,7 @@ int toyni_ntt_ctx_trim(toyni_ntt_ctx* c) {
     return TOYNI_OK;
 }
 
+#ifdef TOYNI_TOOLS  // include/toyni_hip_tools.h
 int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, int inverse, int reps, float* ms_per_pass, void* stream) {
     if (!c || !d_data || !ms_per_pass) return TOYNI_E_NULL;
     if (reps < 1 || batch < 1) return TOYNI_E_RANGE;
@@ -1842,36 +1823,7 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
     if (!ok) return TOYNI_E_INVALID_SIZE;
     return (int)err;
 }
-
-int toyni_microbench(int which, int iters, int blocks, float* ms_out, uint32_t* sink_out) {
-    if (!ms_out) return TOYNI_E_NULL;
-    uint32_t* d_sink = nullptr;
-    HIPCHK(hipMalloc((void**)&d_sink, 2 * sizeof(uint32_t)));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    auto launch = [&](int it) {
-        switch (which) {
-            case 0: hipLaunchKernelGGL(microbench_kernel<0>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-            case 1: hipLaunchKernelGGL(microbench_kernel<1>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-            case 2: hipLaunchKernelGGL(microbench_kernel<2>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-            case 3: hipLaunchKernelGGL(microbench_kernel<3>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-            case 4: hipLaunchKernelGGL(microbench_kernel<4>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-            default: hipLaunchKernelGGL(microbench_kernel<5>, dim3(blocks), dim3(256), 0, 0, 12345u, it, d_sink); break;
-        }
-    };
-    launch(iters / 8 + 1);  // warm
-    HIPCHK(hipEventRecord(e0, 0));
-    launch(iters);
-    HIPCHK(hipEventRecord(e1, 0));
-    HIPCHK(hipEventSynchronize(e1));
-    HIPCHK(hipEventElapsedTime(ms_out, e0, e1));
-    if (sink_out) HIPCHK(hipMemcpy(sink_out, d_sink + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(d_sink);
-    return TOYNI_OK;
-}
+#endif  // TOYNI_TOOLS
 
 // ---- the reference's ABI, symbol for symbol (include/toyni_hip.h section 1) ----
 void* ntt_ctx_create(uint32_t n) {

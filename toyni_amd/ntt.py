@@ -171,18 +171,29 @@ class NttContext:
     def run_device_u64(self, d_data: int, batch: int, inverse: bool, stream: int = 0) -> None:
         check(lib.toyni_ntt_device_u64(self.handle, d_data, batch, int(inverse), stream or None), "GPU NTT failed")
 
+    # ---- measurement build only (libtoyni_hip_tools.so via TOYNI_LIB_OVERRIDE; include/toyni_hip_tools.h) ----
+    @staticmethod
+    def _need_tools():
+        from . import _lib
+        if not _lib.HAS_TOOLS:
+            raise RuntimeError("launch timing hooks exist only in the measurement build: build libtoyni_hip_tools.so "
+                               "(__graft_entry__.build_tools()) and point TOYNI_LIB_OVERRIDE at it")
+
     def profile_passes(self, d_data: int, batch: int, inverse: bool, reps: int = 20, stream: int = 0):
-        """Average launch duration (ms) of each pass kernel, HIP events on `stream` (bench.py's roofline)."""
+        """Average launch duration (ms) of each pass kernel, HIP events on `stream`."""
+        self._need_tools()
         out = (ctypes.c_float * 3)()
         check(lib.toyni_ntt_profile_passes(self.handle, d_data, batch, int(inverse), reps, out, stream or None), "profile failed")
         return [out[i] for i in range(self.passes)]
 
     def timing(self, enable: bool) -> None:
         """Bracket every pass launch of this context with HIP events on its launch stream (see read_timing)."""
+        self._need_tools()
         check(lib.toyni_ntt_ctx_timing(self.handle, int(enable)), "timing switch failed")
 
     def read_timing(self):
         """{'forward': [avg ms per launch of pass 0, ...], 'inverse': [...], 'launches': {...}} for the launches since timing(True)."""
+        self._need_tools()
         ms = (ctypes.c_float * 6)()
         cnt = (ctypes.c_uint32 * 6)()
         check(lib.toyni_ntt_ctx_timing_read(self.handle, ms, cnt), "timing read failed")
