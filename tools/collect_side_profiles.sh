@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): rocprofv3 evidence for the kernels that are not the headline pass kernels.
+#   fold     : fri_fold_kernel<true> on a 2^27 layer (tools/foldbench.py): --kernel-trace --stats, then FETCH_SIZE / WRITE_SIZE
+#   latency  : the single-transform kernels (three-step shapes), n = 2^16 .. 2^22 at batch 1: --kernel-trace --stats
+# Output: gpurun_out/profiles_<tag>_side/ ; tools/summarize_side_profiles.py turns it into profiles/<tag>_fold_stats.csv etc.
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/profiles_${TAG}_side
+mkdir -p $OUT
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fold_stats -- python3 tools/foldbench.py > $OUT/fold_stats.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fold_fetch -- python3 tools/foldbench.py > $OUT/fold_fetch.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/fold_write -- python3 tools/foldbench.py > $OUT/fold_write.log 2>&1 || exit 1
+LAT_RANGE=16:23 LAT_BATCHES=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/latency_stats -- python3 tools/latency.py > $OUT/latency_stats.log 2>&1 || exit 1
+echo "side profiles collected in $OUT"
