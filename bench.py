@@ -41,9 +41,11 @@ def parse():
                     help="do not bracket the pass launches of the timed region with HIP events (A/B check of their cost)")
     ap.add_argument("--probe-ranks", action="store_true",
                     help="launch check without a GPU: the ranks rendezvous over gloo, count themselves and exit (tests/test_bench_launch.py)")
-    ap.add_argument("--workload", choices=["batch", "fourstep", "slab"], default="batch",
+    ap.add_argument("--exchange", choices=["peer", "rccl"], default="peer", help="slab-sp workload: how the one exchange moves its blocks")
+    ap.add_argument("--workload", choices=["batch", "fourstep", "slab", "slab-sp"], default="batch",
                     help="batch: the default sharded batch (weak scaling); fourstep: ONE transform of n = 2^log-n split over "
-                         "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit)")
+                         "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit); slab-sp: the same "
+                         "transform driven from ONE process over --gpus devices through the C ABI (toyni_ntt_slab_multi_gpu_device)")
     return ap.parse_args()
 
 
@@ -171,6 +173,55 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def bench_slab_single_process(args):
+    """ONE process, --gpus devices: the slab transform behind the C ABI (include/toyni_hip.h 2c).  With fewer devices than lanes
+    (TOYNI_BENCH_LANES_ON_ONE_DEVICE=1, e.g. the 1-GPU box) every lane sits on device 0 and the exchange is a local copy."""
+    import torch
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import toyni_amd
+    from toyni_amd import dist as tdist
+    lanes = args.gpus
+    one_dev = os.environ.get("TOYNI_BENCH_LANES_ON_ONE_DEVICE") == "1" or torch.cuda.device_count() < lanes
+    devices = [0] * lanes if one_dev else list(range(lanes))
+    log_n = args.log_n
+    n = 1 << log_n
+    l1, ls = tdist.slab_split(log_n, lanes)
+    exchange = toyni_amd.ntt.EXCHANGE_RCCL if args.exchange == "rccl" else toyni_amd.ntt.EXCHANGE_PEER_COPY
+    slabs, rows, keep = [], [], []
+    for g, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x51AB + g)
+        slabs.append(torch.randint(0, P, (n // lanes,), dtype=torch.int32, device=dev, generator=gen))
+        rows.append(torch.empty(n // lanes, dtype=torch.int32, device=dev))
+        keep.append(slabs[-1].clone())
+    sp, rp = [t.data_ptr() for t in slabs], [t.data_ptr() for t in rows]
+
+    def step():
+        toyni_amd.ntt_slab_multi_gpu_device(n, devices, sp, rp, False, exchange)
+        toyni_amd.ntt_slab_multi_gpu_device(n, devices, sp, rp, True, exchange)
+
+    for _ in range(args.warmup):
+        step()
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()                                   # the entry point blocks until every lane is done
+    wall = time.perf_counter() - t0
+    assert all(torch.equal(a, b) for a, b in zip(slabs, keep)), "round trip changed the data"
+    print(json.dumps({
+        "metric": "BabyBear NTT throughput, single transform split over GPUs from one process (slab form, one exchange)",
+        "value": 2 * args.steps * n / wall, "unit": "elements/s", "n_gpus": len(set(devices)), "lanes": lanes, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"forward+inverse slab-form NTT n=2^{log_n} (M1=2^{l1} x S1=2^{ls}) over {lanes} lane(s) on device(s) {sorted(set(devices))}, "
+                               f"single process, exchange by {'RCCL grouped send/recv' if args.exchange == 'rccl' else 'hipMemcpyPeerAsync'}",
+                   "log_n": log_n, "parallelism": f"column/row split x{lanes}, one exchange"},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def probe_ranks(args):
     """What `--gpus N` starts, checked without a GPU: every rank joins a gloo group and adds 1; rank 0 prints the count."""
     import torch
@@ -254,9 +305,11 @@ def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
         cfile = tfile.replace("_traffic", "_counters")
         if os.path.exists(cfile):
             cj = json.load(open(cfile))
-            insts = [c.get("SQ_INSTS_VALU") for kk, c in cj.items() if "ntt_pass" in kk and kk in tj["kernels"]]
-            if insts and all(insts):
-                lane_ops = sum(insts) * 64.0 / (n * batch)
+            ks = [c for kk, c in cj.items() if "ntt_pass" in kk and kk in tj["kernels"] and c.get("SQ_INSTS_VALU") and c.get("dispatches")]
+            if ks:
+                # a 3-pass plan launches its column-pass kernel twice per transform: weight every kernel by its launches per transform
+                dmin = min(c["dispatches"] for c in ks)
+                lane_ops = sum(c["SQ_INSTS_VALU"] * c["dispatches"] / dmin for c in ks) * 64.0 / (n * batch)
                 ach = lane_ops * n * batch / t_fwd_s / 1e12
                 valu = {"lane_ops_per_element_per_transform": lane_ops, "achieved_Tops": ach, "peak_Tops": 39.3, "frac": ach / 39.3,
                         "note": "forward transform; peak = the 4-cycle instruction class (mul/mad/min/add3) at 2.4 GHz; add/sub/xor issue "
@@ -267,6 +320,8 @@ def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
 
 def main():
     args = parse()
+    if args.workload == "slab-sp":
+        return bench_slab_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.probe_ranks:
@@ -657,6 +712,29 @@ def main():
                                                       "note": "harness wall time, one proof, warm, median of 3; the reference prover is infeasible at this size (O(n^3) interpolation, SURVEY F5)"}
         except Exception as exc:
             extras["fib_prove_trace2^16_blowup32"] = {"ms": None, "error": str(exc)[:300]}
+
+        # one 2^27 transform through the single-process multi-GPU entry point (include/toyni_hip.h 2c), 8 lanes on this one device
+        try:
+            ln27, lanes27 = 27, 8
+            sl = [torch.randint(0, P, ((1 << ln27) // lanes27,), dtype=torch.int32, device=dev) for _ in range(lanes27)]
+            rw = [torch.empty_like(t) for t in sl]
+            spp, rpp = [t.data_ptr() for t in sl], [t.data_ptr() for t in rw]
+
+            def slab_sp():
+                toyni_amd.ntt_slab_multi_gpu_device(1 << ln27, [dev.index] * lanes27, spp, rpp, False)
+                toyni_amd.ntt_slab_multi_gpu_device(1 << ln27, [dev.index] * lanes27, spp, rpp, True)
+
+            slab_sp()
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            for _ in range(5):
+                slab_sp()
+            extras["slab_2^27_single_process_8_lanes_on_one_gpu"] = {
+                "ms_per_fwd_inv": (time.perf_counter() - t0s) / 5 * 1e3,
+                "note": "toyni_ntt_slab_multi_gpu_device: slab pass, 64 local block copies standing in for the xGMI exchange, relayout, row transforms; blocking calls"}
+            del sl, rw
+        except Exception as exc:
+            extras["slab_2^27_single_process_8_lanes_on_one_gpu"] = {"error": str(exc)[:300]}
 
         # the reference-shaped fold call fri_fold(evals, xs, beta) on host slices (src/math/fri.rs:27-48), PCIe inclusive
         hm = 1 << 20
