@@ -511,6 +511,10 @@ int main(int argc, char** argv) {
             pass3_max_log_tiles32() = std::atoi(argv[i] + 1);
             continue;
         }
+        if (argv[i][0] == 'w') {                    // "wN": launches of >= 2^N 32-wide tiles take the 64-wide shapes of the 128/256-point passes
+            wide_min_log_tiles32() = std::atoi(argv[i] + 1);
+            continue;
+        }
         if (argv[i][0] == 'l') {                    // "lLOGxZ": low-degree extension of 2^(LOG-Z) coefficients to 2^LOG points
             test_lde(std::atoi(argv[i] + 1), 2, xb ? std::atoi(xb + 1) : 5, 7);
             std::printf("lde %s failures=%d\n", argv[i], failures);

@@ -17,6 +17,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <memory>
+
 // ---- per-(device, lane, n) context cache: process lifetime, never destroyed (src/ntt.rs:128-141) ----
 namespace {
 
@@ -118,20 +120,24 @@ int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
     for (int d = 0; d < ndev; ++d) if (devices[d] < 0 || devices[d] >= count) return TOYNI_E_RANGE;
-    SlabGroup* g = new SlabGroup();
+    // the shape is checked on the first lane's context before anything else is allocated
+    toyni_ntt_ctx* first = nullptr;
+    MG_TRY(cached_ctx(devices[0], 0, n, &first));
+    const size_t m1 = toyni_ntt_ctx_first_pass_points(first);
+    if (!m1) return TOYNI_E_INVALID_SIZE;  // n <= 1024: a single pass, nothing to split
+    const size_t s1 = (size_t)n / m1;
+    if (s1 / (size_t)ndev < 32 || m1 < (size_t)ndev) return TOYNI_E_RANGE;
+    std::unique_ptr<SlabGroup> owner(new SlabGroup());  // released into the registry only when complete
+    SlabGroup* g = owner.get();
     g->n = n;
+    g->m1 = m1;
+    g->s1 = s1;
     g->lanes.resize((size_t)ndev);
     for (int d = 0; d < ndev; ++d) {
         SlabLane& L = g->lanes[(size_t)d];
         L.device = devices[d];
         const int lane = lane_of(devices, d);
         MG_TRY(cached_ctx(L.device, lane, n, &L.big));
-        if (d == 0) {
-            g->m1 = toyni_ntt_ctx_first_pass_points(L.big);
-            if (!g->m1) return TOYNI_E_INVALID_SIZE;  // n <= 1024: a single pass, nothing to split
-            g->s1 = (size_t)n / g->m1;
-            if (g->s1 / (size_t)ndev < 32 || g->m1 < (size_t)ndev) return TOYNI_E_RANGE;
-        }
         MG_TRY(cached_ctx(L.device, lane, (uint32_t)g->s1, &L.row));
         DeviceGuard guard(L.device);
         MG_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -148,6 +154,7 @@ int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
             if (devices[p] != L.device && hipDeviceEnablePeerAccess(devices[p], 0) != hipSuccess) (void)hipGetLastError();
     }
     groups.emplace(std::make_pair(key, n), g);
+    owner.release();
     *out = g;
     return TOYNI_OK;
 }
@@ -180,6 +187,7 @@ int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPt
         if (api.GroupStart() != 0) return TOYNI_E_RCCL;
         for (size_t a = 0; a < G; ++a) {
             SlabLane& L = g->lanes[a];
+            DeviceGuard guard(L.device);      // the communicator's device is current while its calls are queued
             for (size_t b = 0; b < G; ++b) {  // in stream order on the lane's compute stream: no events needed
                 if (api.Send(send(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;
                 if (api.Recv(recv(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;

@@ -148,6 +148,18 @@ inline int& pass3_max_log_tiles32() {
     return v;
 }
 
+// experiment switches (compile time): tile width (log2) of the wide variants of the 128-point and the 512-point passes
+#ifndef TOYNI_WIDE_43
+#define TOYNI_WIDE_43 6
+#endif
+#ifndef TOYNI_WIDE_54
+#define TOYNI_WIDE_54 6
+#endif
+inline int& wide_min_log_tiles32() {
+    static int v = 10;
+    return v;
+}
+
 template <class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
@@ -172,18 +184,30 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
         else TOYNI_PASS_GO(K, A, B, 3);                                                \
         return true;                                                                   \
     }
+    // The 128-, 256- and 512-point passes (three-pass plans n >= 2^21, two-pass plans up to 2^19) are memory-bound, and the strided
+    // pattern moves more with 256-byte row segments than with 128-byte ones (tools/membench.hip: 4.85 against 4.4 TB/s): large
+    // launches take 64-wide tiles (wide_min_log_tiles32(): launches of at least that many 32-wide tiles; a huge value = never).
+    // Measured (profiles/r02_ab_wide.txt): +7.7 % at 64 x 2^24, +6 % at 2^21 / 2^22, +5.4 % at 2^27, +3.8 % at 2^18; 128-wide tiles for
+    // the 128-point passes add another 0.7-1.5 % at 2^21 / 2^22 and lose 0.3 % at 2^13 / 2^14 (not taken).  The 1024-point passes
+    // of n = 2^20 cannot widen: a 64 x 1024 tile is 256 KiB.
+#define TOYNI_PASS_CASE_WIDE(K, A, B, LCW)                                            \
+    if (kind == K && log_m == (A) + (B)) {                                             \
+        if (log_tiles32 >= wide_min_log_tiles32() + ((LCW) - 6)) TOYNI_PASS_GO(K, A, B, LCW); \
+        else TOYNI_PASS_GO(K, A, B, 5);                                                \
+        return true;                                                                   \
+    }
     // strided column passes (first / middle passes of a 2- or 3-pass transform)
     TOYNI_PASS_CASE(KIND_COL, 3, 3, 5)
-    TOYNI_PASS_CASE(KIND_COL, 4, 3, 5)
-    TOYNI_PASS_CASE(KIND_COL, 4, 4, 5)
-    TOYNI_PASS_CASE(KIND_COL, 5, 4, 5)
+    TOYNI_PASS_CASE_WIDE(KIND_COL, 4, 3, TOYNI_WIDE_43)
+    TOYNI_PASS_CASE_WIDE(KIND_COL, 4, 4, 6)
+    TOYNI_PASS_CASE_WIDE(KIND_COL, 5, 4, TOYNI_WIDE_54)
     TOYNI_PASS_CASE_W(KIND_COL, 5, 5)
     // last pass of a multi-pass transform: contiguous rows in, transposed (natural order) out
     TOYNI_PASS_CASE(KIND_ROW_T, 5, 0, 6)
     TOYNI_PASS_CASE(KIND_ROW_T, 3, 3, 5)
-    TOYNI_PASS_CASE(KIND_ROW_T, 4, 3, 5)
-    TOYNI_PASS_CASE(KIND_ROW_T, 4, 4, 5)
-    TOYNI_PASS_CASE(KIND_ROW_T, 5, 4, 5)
+    TOYNI_PASS_CASE_WIDE(KIND_ROW_T, 4, 3, TOYNI_WIDE_43)
+    TOYNI_PASS_CASE_WIDE(KIND_ROW_T, 4, 4, 6)
+    TOYNI_PASS_CASE_WIDE(KIND_ROW_T, 5, 4, TOYNI_WIDE_54)
     TOYNI_PASS_CASE_W(KIND_ROW_T, 5, 5)
     // single-pass transforms (n <= 1024): one row per batch entry
     TOYNI_PASS_CASE(KIND_ROW_N, 1, 0, 6)
@@ -197,6 +221,7 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
     TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 4)
     TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
 #undef TOYNI_PASS_CASE
+#undef TOYNI_PASS_CASE_WIDE
 #undef TOYNI_PASS_CASE_W
 #undef TOYNI_PASS_GO
     return false;

@@ -994,6 +994,7 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     c->device = device;
     if (!build_plan(ilog2(n), c->plan)) { delete c; return TOYNI_E_INVALID_SIZE; }
     if (const char* env = std::getenv("TOYNI_CHUNK_ELEMS")) c->chunk_elems = (size_t)std::strtoull(env, nullptr, 0);
+    if (const char* env = std::getenv("TOYNI_WIDE_TILES")) wide_min_log_tiles32() = std::atoi(env);  // tuning knob (99: never the 64-wide shapes)
     if (const char* env = std::getenv("TOYNI_P3_TILES")) pass3_max_log_tiles32() = std::atoi(env);  // tuning knob (-1: never the three-step shapes)
     {
         hipDeviceProp_t prop;
