@@ -405,7 +405,9 @@ inline bool slab_pass(const NttPlan& plan, const uint32_t* tables, bool inverse,
         a.tw_hi = ones;
         a.scale = to_mont_host(bb_inv_host((uint32_t)(1u << pp.log_m)));
     }
-    return dispatch_pass(KIND_COL, pp.log_m, log_c - 5, [&](auto pass) {
+    int log_tiles32 = log_c - 5;
+    if (log_c < 6 && log_tiles32 >= wide_min_log_tiles32()) log_tiles32 = wide_min_log_tiles32() - 1;  // a 32-column slab cannot hold a 64-wide tile
+    return dispatch_pass(KIND_COL, pp.log_m, log_tiles32, [&](auto pass) {
         using P = decltype(pass);
         launch(pass, a, cols_local / P::C);
     });
