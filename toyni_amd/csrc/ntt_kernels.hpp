@@ -39,6 +39,7 @@ struct PassArgs {
     const uint32_t* in;
     uint32_t* out;
     const uint32_t* stage_tw;  // packed per-stage table of this pass' M: [2^t - 1 + x] = w_{2^(t+1)}^x, Montgomery form
+    const uint32_t* stage_tw3; // radix-4 companion: block t (t >= 1) at [2^t - 2]: w_{2^(t+1)}^(3x), then -w_{2^(t+1)}^(3x + 2^(t-1)), x < 2^(t-1)
     const uint32_t* tw_lo;     // KIND_COL: w_L^x,               x < 2^tw_lowbits  (Montgomery form)
     const uint32_t* tw_hi;     // KIND_COL: w_L^(y << tw_lowbits), y < L >> tw_lowbits
     uint32_t tw_lowbits;
@@ -145,7 +146,9 @@ struct Pass {
 
     // occupancy target: workgroups per CU by LDS (160 KiB), expressed as waves per SIMD for __launch_bounds__
     // (capped at 4: with the prefetch pipeline 16 waves per CU hide the rest, and 128 VGPRs are needed)
-    static constexpr uint32_t lds_wg_per_cu() { return LDS_WORDS ? (160u * 1024u) / ((LDS_WORDS + (TWO_STEP ? M - E2 : 0u)) * 4u) : 8u; }
+    static constexpr uint32_t lds_wg_per_cu() {
+        return LDS_WORDS ? (160u * 1024u) / ((LDS_WORDS + (TWO_STEP ? 2u * M - 3u * E2 : 0u)) * 4u) : 8u;  // + both twiddle slices
+    }
     static constexpr uint32_t min_waves_per_simd() {
         uint32_t w = (lds_wg_per_cu() * (T / 64u ? T / 64u : 1u) + 3u) / 4u;
         return w < 1u ? 1u : (w > 4u ? 4u : w);
@@ -380,9 +383,69 @@ struct Pass {
         }
     }
 
-    template <int LE, int SHIFT>
-    static TOYNI_HD void stages(uint32_t (&x)[1 << LE], const uint32_t* tw1, uint32_t low, const uint32_t* uni) {
+    // ---- radix-4 form of the per-thread stages (SHIFT > 0): the same group, twiddles from tables ----
+    // With e = low + (q << SHIFT) the five multipliers of a group are W^e, W^(e+2^(t-1)) (stage t = s + SHIFT), V^e = W^(2e) (stage
+    // t-1), W^(3e) and -W^(3e+2^(t-1)).  The first three are entries of the packed stage table; the last two come from its radix-4
+    // companion `tw3` (same size, PassArgs::stage_tw3) -- W^(3e) wraps past W^(2^t) = -1 at a thread-dependent point, so deriving
+    // it from the stage table would cost a sign fix-up per thread and twiddle.  Besides the 3 instructions per group this form needs
+    // ONE negated twiddle per q (for the dot_sub) where two radix-2 stages need three.
+    // tw1: the stage table from stage SHIFT on; tw3: the companion from block SHIFT + 1 on.
+    template <int LE, int SHIFT, int S>
+    static TOYNI_HD void stages_thread_r4(uint32_t (&x)[1 << LE], const uint32_t* tw1, const uint32_t* tw3, uint32_t low) {
+        // `low` is made opaque: knowing low < 2^SHIFT the compiler turns every table address into (low << 2) | constant -- one
+        // VGPR per table entry, all loop-invariant, all hoisted out of the tile loop (51 of them: spills).  As an opaque value the
+        // addresses stay (one register) + (immediate offset).
+        TOYNI_PIN(low);
+        if constexpr (S >= 1) {
+            constexpr int t = S + SHIFT;
+            constexpr uint32_t D = 1u << S, DP = 1u << (S - 1), HALF = 1u << (t - 1);
+            const uint32_t* t1 = tw1 + ((1u << t) - (1u << SHIFT));
+            const uint32_t* t2 = tw1 + (HALF - (1u << SHIFT));
+            const uint32_t* t3 = tw3 + ((1u << t) - (2u << SHIFT));
+            // q outermost: the five multipliers of one q are live only while its 2^(LE-1-S) groups are processed (loading all
+            // DP sets up front, as the radix-2 form does with its 2 x 16, would put 6 x DP + 32 values in flight: spills at DP = 8)
+            // software-pipelined by one q: the next q's five table reads are issued before this q's groups are computed, and a
+            // scheduling fence per q keeps the compiler from hoisting all of them to the top
+            uint32_t n1 = t1[low], n1p = t1[low + HALF], n2 = t2[low], n3 = t3[low], n3n = t3[HALF + low];
+#pragma unroll
+            for (uint32_t q = 0; q < DP; ++q) {
+                const uint32_t w1 = n1, w1p = n1p, w2 = n2, nw2 = BB_P - n2, w3 = n3, w3n = n3n;
+                if (q + 1 < DP) {
+                    const uint32_t e1 = low + ((q + 1) << SHIFT);
+                    n1 = t1[e1]; n1p = t1[e1 + HALF]; n2 = t2[e1]; n3 = t3[e1]; n3n = t3[HALF + e1];
+                }
+                TOYNI_SCHED_FENCE();
+#pragma unroll
+                for (uint32_t hi = 0; hi < (1u << (LE - 1 - S)); ++hi) {
+                    const uint32_t i = (hi << (S + 1)) | q;
+                    const uint32_t a = x[i], b = x[i + DP], c = x[i + D], e = x[i + D + DP];
+                    const uint32_t s0 = bb_add(a, c), s1 = bb_add(b, e), d0 = bb_sub(a, c), d1 = bb_sub(b, e);
+                    x[i] = bb_add(s0, s1);
+                    x[i + DP] = mont_dot_sub(s0, s1, w2, nw2);
+                    x[i + D] = mont_dot2(d0, w1, d1, w1p);
+                    x[i + D + DP] = mont_dot2(d0, w3, d1, w3n);
+                }
+            }
+            stages_thread_r4<LE, SHIFT, S - 2>(x, tw1, tw3, low);
+        } else if constexpr (S == 0) {   // one stage left: span 2^(SHIFT+1), twiddle w_{2^(SHIFT+1)}^low
+            const uint32_t w = tw1[low], nw = BB_P - w;
+#pragma unroll
+            for (uint32_t i = 0; i < (1u << LE); i += 2) {
+                const uint32_t u = x[i], v = x[i + 1];
+                x[i] = bb_add(u, v);
+                x[i + 1] = mont_dot_sub(u, v, w, nw);
+            }
+        }
+    }
+
+    // R4T: the caller supplies the radix-4 companion table `tw3` for the per-thread stages (SHIFT > 0)
+    template <int LE, int SHIFT, bool R4T = false>
+    static TOYNI_HD void stages(uint32_t (&x)[1 << LE], const uint32_t* tw1, uint32_t low, const uint32_t* uni, const uint32_t* tw3 = nullptr) {
 #if !defined(TOYNI_NO_RADIX4)
+        if constexpr (R4T && SHIFT > 0 && LE >= 2) {
+            stages_thread_r4<LE, SHIFT, LE - 1>(x, tw1, tw3, low);
+            return;
+        }
         if constexpr (SHIFT == 0 && LE >= 2) {
             stages_uniform_r4<LE, LE - 1>(x, uni);
             return;
@@ -444,6 +507,14 @@ struct Pass {
     // step-1 slice of the packed stage table: stages LE2 .. LM-1 = words [2^LE2 - 1, 2^LM - 1)
     static constexpr uint32_t TW1_WORDS = TWO_STEP ? M - E2 : 0;
     static TOYNI_HD const uint32_t* tw1_global(const PassArgs& a) { return a.stage_tw + (E2 - 1u); }
+    // step-1 slice of the radix-4 companion table: blocks LE2 + 1 .. LM - 1 = words [2^(LE2+1) - 2, 2^LM - 2)
+#if defined(TOYNI_NO_RADIX4) || defined(TOYNI_NO_RADIX4_THREAD)   // A/B builds
+    static constexpr bool STEP1_R4 = false;
+#else
+    static constexpr bool STEP1_R4 = TWO_STEP && LE1 >= 2;
+#endif
+    static constexpr uint32_t TW3_WORDS = STEP1_R4 ? M - 2u * E2 : 0;
+    static TOYNI_HD const uint32_t* tw3_global(const PassArgs& a) { return a.stage_tw3 + (2u * E2 - 2u); }
 
     // the wave-uniform twiddles of the last LU stage bits: w_{2^LU}^q, q < 2^(LU-1) = stage LU-1 of the packed table
     static constexpr int LU = TWO_STEP ? LE2 : LE1;
@@ -513,11 +584,11 @@ struct Pass {
     // (b) the LE1 high-bit stages in registers, then park the tile in LDS (two-step) or finish (single-step)
     template <int LZ = 0>
     static TOYNI_HD void step1(const PassArgs& a, const Tile& t, uint32_t tid, uint32_t (&x)[E1], uint32_t* lds, const Uniform& uni,
-                               const uint32_t* tw1) {
+                               const uint32_t* tw1, const uint32_t* tw3) {
         static_assert(LZ == 0 || TWO_STEP, "zero-padded input needs a two-step pass");
         uint32_t c, lo;
         coords1(tid, c, lo);
-        if constexpr (LZ == 0) stages<LE1, LE2>(x, tw1, lo, uni.w);
+        if constexpr (LZ == 0) stages<LE1, LE2, STEP1_R4>(x, tw1, lo, uni.w, tw3);
         else stages_lz<LE1, LE2, LZ, LE1 - 1>(x, tw1, lo, uni.w);
         if (TWO_STEP) {
             const uint32_t base = lds_word(c, 0u, lo);
@@ -571,7 +642,7 @@ struct Pass {
         uint32_t x[E1];
         load_tile<0, E1, LZ>(a, t, tid, x);
         in_scale<LZ>(a, in_seed_issue(a, t, tid), x);
-        step1<LZ>(a, t, tid, x, lds, load_uniform(a), tw1_global(a));
+        step1<LZ>(a, t, tid, x, lds, load_uniform(a), tw1_global(a), tw3_global(a));
     }
     static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
         const Tile t = tile_of(a, tile_id);

@@ -22,7 +22,7 @@ struct PassPlan {
     int log_m;     // log2 of this pass' sub-transform size
     int log_s;     // KIND_COL: log2(columns per prefix block) = log2(n / (M_1..M_p))
     // offsets (in u32 words) into the direction's table blob
-    uint32_t stage_off;
+    uint32_t stage_off, stage3_off;
     uint32_t lo_off, hi_off, lowbits;
 };
 
@@ -56,6 +56,26 @@ inline void append_stage_table(std::vector<uint32_t>& blob, int log_m, uint32_t 
         for (uint32_t x = 0; x < (1u << t); ++x) {
             blob.push_back(to_mont_host(cur));
             cur = bb_mul_host(cur, w_len);
+        }
+    }
+}
+
+// radix-4 companion of the stage table (Pass::stages_thread_r4): for t = 1 .. log_m - 1 and W = w_{2^(t+1)}, block t at offset
+// 2^t - 2 holds W^(3x) for x < 2^(t-1), then -W^(3x + 2^(t-1)) for x < 2^(t-1).  2^log_m - 2 words.
+inline void append_stage3_table(std::vector<uint32_t>& blob, int log_m, uint32_t w_m) {
+    for (int t = 1; t < log_m; ++t) {
+        const uint32_t w_len = bb_pow_host(w_m, 1ull << (log_m - (t + 1)));
+        const uint32_t w3 = bb_mul_host(bb_mul_host(w_len, w_len), w_len);
+        const uint32_t quarter = bb_pow_host(w_len, 1ull << (t - 1));
+        uint32_t cur = 1;
+        for (uint32_t x = 0; x < (1u << (t - 1)); ++x) {
+            blob.push_back(to_mont_host(cur));
+            cur = bb_mul_host(cur, w3);
+        }
+        cur = quarter;
+        for (uint32_t x = 0; x < (1u << (t - 1)); ++x) {
+            blob.push_back(to_mont_host(BB_P - cur));   // never 0: a power of a root of unity
+            cur = bb_mul_host(cur, w3);
         }
     }
 }
@@ -105,12 +125,14 @@ inline bool build_plan(int log_n, NttPlan& plan) {
             const uint32_t w_m = bb_pow_host(w, 1ull << (log_n - pp.log_m));
             const uint32_t stage_off = (uint32_t)blob.size();
             append_stage_table(blob, pp.log_m, w_m);
+            const uint32_t stage3_off = (uint32_t)blob.size();
+            append_stage3_table(blob, pp.log_m, w_m);
             uint32_t lo_off = 0, hi_off = 0, lowbits = 0;
             if (pp.kind == KIND_COL) {
                 const uint32_t w_l = bb_pow_host(w, 1ull << (log_n - log_l));
                 append_two_level(blob, log_l, w_l, 1u, lo_off, hi_off, lowbits);
             }
-            if (dir == 0) { pp.stage_off = stage_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
+            if (dir == 0) { pp.stage_off = stage_off; pp.stage3_off = stage3_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
             consumed += pp.log_m;
         }
         if (log_n >= 11 && log_n <= 15) {
@@ -290,6 +312,7 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         a.in = p == 0 ? src : work;
         a.out = p == plan.npasses - 1 ? dst : work;
         a.stage_tw = tables + pp.stage_off;
+        a.stage_tw3 = tables + pp.stage3_off;
         a.tw_lo = tables + pp.lo_off;
         a.tw_hi = tables + pp.hi_off;
         a.tw_lowbits = pp.lowbits;
@@ -392,6 +415,7 @@ inline bool slab_pass(const NttPlan& plan, const uint32_t* tables, bool inverse,
     a.in = slab;
     a.out = slab;
     a.stage_tw = tables + pp.stage_off;
+    a.stage_tw3 = tables + pp.stage3_off;
     a.tw_lowbits = pp.lowbits;
     a.log_S = (uint32_t)log_c;
     a.in_prefix_log = (uint32_t)(log_c + pp.log_m);

@@ -46,7 +46,7 @@ template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
 // (the zero padding is implied): fewer loads, and the top LZ stages of step 1 degenerate to one multiply per output.
 template <class P, int PF, int LZ = 0>
 __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const PassArgs a, const uint32_t ntiles) {
-    __shared__ uint32_t lds[(P::LDS_WORDS + P::TW1_WORDS) ? (P::LDS_WORDS + P::TW1_WORDS) : 1];
+    __shared__ uint32_t lds[(P::LDS_WORDS + P::TW1_WORDS + P::TW3_WORDS) ? (P::LDS_WORDS + P::TW1_WORDS + P::TW3_WORDS) : 1];
     const uint32_t tid = threadIdx.x;
     if constexpr (!P::TWO_STEP) {
         static_assert(LZ == 0, "single-step passes take whole inputs");
@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
         uint32_t v = blockIdx.x;
         if (v >= ntiles) return;
         uint32_t* lds_tw1 = lds + P::LDS_WORDS;
+        uint32_t* lds_tw3 = lds_tw1 + P::TW1_WORDS;   // radix-4 companion of the step-1 stage twiddles
         uint32_t x[P::E1];
         typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
         P::template load_tile<0, NPF, LZ>(a, t, tid, x);
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
         typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
         const typename P::Uniform uni = P::load_uniform(a);  // step-2 twiddles, SGPR-resident for the whole loop
         for (uint32_t j = tid; j < P::TW1_WORDS; j += P::T) lds_tw1[j] = P::tw1_global(a)[j];
+        for (uint32_t j = tid; j < P::TW3_WORDS; j += P::T) lds_tw3[j] = P::tw3_global(a)[j];
         TOYNI_WAIT_VMEM0();  // the first tile's loads have landed: the loop is entered with no load pending on any path
         __syncthreads();
         while (true) {
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass_kernel(const Pass
             else TOYNI_WAIT_VMEM0();
             P::template load_tile<NPF, P::E1, LZ>(a, t, tid, x);
             P::template in_scale<LZ>(a, inraw, x);  // forward coset FFT only (uniform branch)
-            P::template step1<LZ>(a, t, tid, x, lds, uni, lds_tw1);
+            P::template step1<LZ>(a, t, tid, x, lds, uni, lds_tw1, lds_tw3);
             typename P::Seeds seeds = P::seeds_finish(a, raw);
 #pragma unroll
             for (uint32_t g = 0; g < P::G2; ++g) { TOYNI_PIN(seeds.g[g].a0); TOYNI_PIN(seeds.g[g].g); }  // materialised HERE
