@@ -147,7 +147,7 @@ struct Pass {
     // occupancy target: workgroups per CU by LDS (160 KiB), expressed as waves per SIMD for __launch_bounds__
     // (capped at 4: with the prefetch pipeline 16 waves per CU hide the rest, and 128 VGPRs are needed)
     static constexpr uint32_t lds_wg_per_cu() {
-        return LDS_WORDS ? (160u * 1024u) / ((LDS_WORDS + (TWO_STEP ? 2u * M - 3u * E2 : 0u)) * 4u) : 8u;  // + both twiddle slices
+        return LDS_WORDS ? (160u * 1024u) / ((LDS_WORDS + (TWO_STEP ? M - E2 : 0u) + ((TWO_STEP && LE1 >= 2 && LC >= 4) ? M - 2u * E2 : 0u)) * 4u) : 8u;  // + the twiddle slices
     }
     static constexpr uint32_t min_waves_per_simd() {
         uint32_t w = (lds_wg_per_cu() * (T / 64u ? T / 64u : 1u) + 3u) / 4u;
@@ -511,8 +511,8 @@ struct Pass {
 #if defined(TOYNI_NO_RADIX4) || defined(TOYNI_NO_RADIX4_THREAD)   // A/B builds
     static constexpr bool STEP1_R4 = false;
 #else
-    static constexpr bool STEP1_R4 = TWO_STEP && LE1 >= 2;
-#endif
+    static constexpr bool STEP1_R4 = TWO_STEP && LE1 >= 2 && LC >= 4;   // the 8-wide shapes keep radix 2: the second table slice would cost
+#endif                                                                  // them their fourth workgroup per CU (LDS)
     static constexpr uint32_t TW3_WORDS = STEP1_R4 ? M - 2u * E2 : 0;
     static TOYNI_HD const uint32_t* tw3_global(const PassArgs& a) { return a.stage_tw3 + (2u * E2 - 2u); }
 
