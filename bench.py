@@ -736,6 +736,32 @@ def main():
         except Exception as exc:
             extras["slab_2^27_single_process_8_lanes_on_one_gpu"] = {"error": str(exc)[:300]}
 
+        # batched host-slice transform (ntt_cuda-shaped, PCIe inclusive): pageable memory (what a Rust Vec is) against pinned
+        # memory from toyni_host_alloc, which takes the pipelined path (upload / kernels / download overlapped)
+        try:
+            hb_n, hb_batch = 1 << 20, 256                                    # 2 GiB of u64
+            hctx = toyni_amd.NttContext(hb_n, device=dev.index)
+            pageable = np.random.default_rng(21).integers(0, P, hb_n * hb_batch, dtype=np.uint64)
+            pinned = toyni_amd.PinnedArray(hb_n * hb_batch)
+            pinned.array[:] = pageable
+            res = {}
+            for name, arr in (("pageable", pageable), ("pinned", pinned.array)):
+                hctx.run_host(arr, False, batch=hb_batch)
+                t0h = time.perf_counter()
+                hctx.run_host(arr, True, batch=hb_batch)
+                hctx.run_host(arr, False, batch=hb_batch)
+                res[name] = (time.perf_counter() - t0h) / 2
+            assert (pinned.array == pageable).all()
+            extras["host_batch_256x2^20"] = {"pageable_ms": res["pageable"] * 1e3, "pinned_pipelined_ms": res["pinned"] * 1e3,
+                                             "pinned_elements_per_s": hb_n * hb_batch / res["pinned"],
+                                             "pinned_GBps_each_way": 8.0 * hb_n * hb_batch / res["pinned"] / 1e9,
+                                             "note": "toyni_ntt_host on 2 GiB of u64 in place; PCIe-bound, never `value`"}
+            pinned.free()
+            del pageable
+            hctx.destroy()
+        except Exception as exc:
+            extras["host_batch_256x2^20"] = {"error": str(exc)[:300]}
+
         # the reference-shaped fold call fri_fold(evals, xs, beta) on host slices (src/math/fri.rs:27-48), PCIe inclusive
         hm = 1 << 20
         he = np.random.default_rng(7).integers(0, P, hm, dtype=np.uint64)

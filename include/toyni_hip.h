@@ -251,6 +251,13 @@ int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* 
  * 4. Plumbing
  * ---------------------------------------------------------------------------------------------- */
 int toyni_malloc(void** d_ptr, size_t bytes);
+/* Pinned (page-locked) host memory.  A host-slice entry point that is handed pinned memory (from here, or registered by the
+ * caller with hipHostRegister) and at least two chunks of data (2 x 64 MiB; TOYNI_PIPE_CHUNK_BYTES) runs pipelined: the upload of
+ * chunk k + 1, the kernels of chunk k and the download of chunk k - 1 overlap on three streams (PCIe is full duplex).  Pageable
+ * memory (a Rust Vec, what the reference passes: src/ntt.rs:233) takes the plain upload - kernels - download path: its copies
+ * are staged by the runtime and do not overlap. */
+int toyni_host_alloc(void** h_ptr, size_t bytes);
+int toyni_host_free(void* h_ptr);
 int toyni_free(void* d_ptr);
 int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);

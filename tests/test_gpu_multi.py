@@ -216,3 +216,31 @@ def test_host_merkle_staging_repeated(ta):
         for s in (None, salts):
             t = ta.MerkleTree(vals, s)
             assert t.root() == oracle.merkle_commit_values(vals, s)[-1][0].tobytes(), (n, s is None)
+
+
+def test_pinned_host_memory_takes_the_pipelined_path(ta):
+    """Host slices in pinned memory (toyni_host_alloc): chunked, double-buffered, upload / kernels / download on three streams.
+    Same values as the plain path on pageable memory, in both directions, with a ragged last chunk and a coset shift."""
+    n, batch = 1 << 18, 100                       # 200 MiB of u64: three 64 MiB chunks of 32 transforms and a ragged one of 4
+    x = oracle.splitmix(n * batch, 9090)
+    ctx = ta.NttContext(n)
+    want = x.copy()
+    ctx.run_host(want, False, batch=batch)        # pageable numpy memory: the plain path
+    for b in (0, 31, 32, 63, 96, 99):
+        assert (want[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n])).all(), b
+    pin = ta.PinnedArray(n * batch)
+    pin.array[:] = x
+    ctx.run_host(pin.array, False, batch=batch)
+    assert (pin.array == want).all()
+    ctx.run_host(pin.array, True, batch=batch)
+    assert (pin.array == x).all()
+    ctx.run_host(pin.array, False, batch=batch, shift=7)
+    want7 = x.copy()
+    ctx.run_host(want7, False, batch=batch, shift=7)
+    assert (pin.array == want7).all()
+    # and through the multi-GPU batch runner (two lanes on the one device, each lane pipelining its own shard)
+    pin.array[:] = x
+    ta.ntt_host_multi_gpu(pin.array, n, [0, 0], inverse=False)
+    assert (pin.array == want).all()
+    pin.free()
+    ctx.destroy()

@@ -8,7 +8,7 @@ library raises.
 """
 from . import _lib  # noqa: F401  (fails loudly if libtoyni_hip.so is missing)
 from .ntt import (  # noqa: F401
-    CudaBuffer, GpuBuffer, NttContext, cuda_available, gpu_available, intt_cuda, intt_gpu, ntt_cuda, ntt_gpu,
+    CudaBuffer, GpuBuffer, NttContext, PinnedArray, cuda_available, gpu_available, intt_cuda, intt_gpu, ntt_cuda, ntt_gpu,
     ntt_host_multi_gpu, ntt_slab_multi_gpu_device, ntt_slab_multi_gpu_host,
 )
 from .fri import fri_fold, fri_fold_device, fri_fold_ext, fri_fold_ext_device, fri_fold_layers_device  # noqa: F401

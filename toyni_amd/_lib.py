@@ -105,6 +105,8 @@ SIGNATURES = {
     # section 4
     "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
     "toyni_free": (c_int, [c_void_p]),
+    "toyni_host_alloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
+    "toyni_host_free": (c_int, [c_void_p]),
     "toyni_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size]),
     "toyni_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size]),
     "toyni_narrow_u64_to_u32": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),

@@ -639,6 +639,17 @@ struct toyni_ntt_ctx {
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
     std::map<uint32_t, ShiftTable> shifts;
+    // Pipelined host-slice path for callers that hand over PINNED host memory (toyni_host_alloc / hipHostRegister): two
+    // staging slots, a copy-in and a copy-out stream next to the compute stream, so that the upload of chunk k + 1, the
+    // kernels of chunk k and the download of chunk k - 1 overlap (PCIe is full duplex).
+    struct HostPipe {
+        hipStream_t in = nullptr, out = nullptr;
+        hipEvent_t in_done[2] = {nullptr, nullptr}, comp_done[2] = {nullptr, nullptr}, out_done[2] = {nullptr, nullptr};
+        uint64_t* d_stage[2] = {nullptr, nullptr};
+        uint32_t* d_data[2] = {nullptr, nullptr};
+        size_t cap_elems = 0;
+        bool ready = false;
+    } pipe;
 #ifdef TOYNI_TOOLS                  // measurement build only (libtoyni_hip_tools.so, include/toyni_hip_tools.h)
     struct TimingRec { hipEvent_t e0, e1; int dir, pass; };
     bool timing = false;             // toyni_ntt_ctx_timing: bracket every pass launch with events
@@ -1024,6 +1035,17 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
         for (auto& r : c->retired) (void)hipFree(r.ptr);
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
+        if (c->pipe.ready) {
+            (void)hipStreamDestroy(c->pipe.in);
+            (void)hipStreamDestroy(c->pipe.out);
+            for (int k = 0; k < 2; ++k) {
+                (void)hipEventDestroy(c->pipe.in_done[k]);
+                (void)hipEventDestroy(c->pipe.comp_done[k]);
+                (void)hipEventDestroy(c->pipe.out_done[k]);
+                (void)hipFree(c->pipe.d_stage[k]);
+                (void)hipFree(c->pipe.d_data[k]);
+            }
+        }
         (void)hipFree(c->d_ones);
 #ifdef TOYNI_TOOLS
         for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -1168,6 +1190,78 @@ int toyni_ntt_device_u64(toyni_ntt_ctx* c, uint64_t* d_data, size_t batch, int i
     return (int)hipGetLastError();
 }
 
+// bytes of one pipeline chunk of the pinned host-slice path (TOYNI_PIPE_CHUNK_BYTES; 0 = never pipeline)
+static size_t pipe_chunk_bytes() {
+    static const size_t v = [] {
+        const char* env = std::getenv("TOYNI_PIPE_CHUNK_BYTES");
+        return env ? (size_t)std::strtoull(env, nullptr, 0) : (size_t)64 << 20;
+    }();
+    return v;
+}
+
+static bool host_pointer_is_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain pageable memory: unknown to the runtime
+    return attr.type == hipMemoryTypeHost;
+}
+
+// chunked, double-buffered, three streams; h_data is pinned.  Caller holds c->mu and the device guard.
+static int host_transform_pipelined(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint32_t shift, int inverse, size_t chunk) {
+    const size_t n = c->n;
+    toyni_ntt_ctx::HostPipe& p = c->pipe;
+    if (!p.ready) {
+        HIPCHK(hipStreamCreateWithFlags(&p.in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&p.out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipEventCreateWithFlags(&p.in_done[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p.comp_done[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p.out_done[k], hipEventDisableTiming));
+        }
+        p.ready = true;
+    }
+    if (p.cap_elems < chunk * n) {
+        HIPCHK(hipStreamSynchronize(p.in));
+        HIPCHK(hipStreamSynchronize(p.out));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 2; ++k) {
+            if (p.d_stage[k]) HIPCHK(hipFree(p.d_stage[k]));
+            if (p.d_data[k]) HIPCHK(hipFree(p.d_data[k]));
+            p.d_stage[k] = nullptr;
+            p.d_data[k] = nullptr;
+        }
+        p.cap_elems = 0;
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipMalloc((void**)&p.d_stage[k], chunk * n * sizeof(uint64_t)));
+            HIPCHK(hipMalloc((void**)&p.d_data[k], chunk * n * sizeof(uint32_t)));
+        }
+        p.cap_elems = chunk * n;
+    }
+    hipStream_t comp = c->stream;
+    size_t k = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
+        const size_t nb = batch - b0 < chunk ? batch - b0 : chunk, elems = nb * n;
+        const int slot = (int)(k & 1);
+        uint64_t* h = h_data + b0 * n;
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(p.in, p.out_done[slot], 0));   // the slot's previous download has left the staging buffer
+        HIPCHK(hipMemcpyAsync(p.d_stage[slot], h, elems * sizeof(uint64_t), hipMemcpyHostToDevice, p.in));
+        HIPCHK(hipEventRecord(p.in_done[slot], p.in));
+        HIPCHK(hipStreamWaitEvent(comp, p.in_done[slot], 0));
+        hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(elems)), dim3(256), 0, comp, (const uint64_t*)p.d_stage[slot], p.d_data[slot], elems);
+        int rc = enqueue_transform(c, p.d_data[slot], p.d_data[slot], nb, inverse != 0, comp, shift);
+        if (rc) return rc;
+        hipLaunchKernelGGL(widen_kernel, dim3(grid_for(elems)), dim3(256), 0, comp, (const uint32_t*)p.d_data[slot], p.d_stage[slot], elems);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(p.comp_done[slot], comp));
+        HIPCHK(hipStreamWaitEvent(p.out, p.comp_done[slot], 0));
+        HIPCHK(hipMemcpyAsync(h, p.d_stage[slot], elems * sizeof(uint64_t), hipMemcpyDeviceToHost, p.out));
+        HIPCHK(hipEventRecord(p.out_done[slot], p.out));
+    }
+    HIPCHK(hipStreamSynchronize(p.out));
+    HIPCHK(hipStreamSynchronize(comp));
+    reclaim_after_sync(c, comp);
+    return TOYNI_OK;
+}
+
 static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint32_t shift, int inverse) {
     if (!c || !h_data) return TOYNI_E_NULL;
     if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
@@ -1175,6 +1269,13 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
     DeviceGuard guard(c->device);
     const size_t total = batch * (size_t)c->n;
     if (!total) return TOYNI_OK;
+    // pinned host memory and more than one chunk's worth of data: upload, kernels and download overlap
+    if (pipe_chunk_bytes() && batch >= 2 && total * sizeof(uint64_t) >= 2 * pipe_chunk_bytes() && host_pointer_is_pinned(h_data)) {
+        size_t chunk = pipe_chunk_bytes() / ((size_t)c->n * sizeof(uint64_t));
+        if (chunk < 1) chunk = 1;
+        if (chunk > (batch + 1) / 2) chunk = (batch + 1) / 2;
+        return host_transform_pipelined(c, h_data, batch, shift, inverse, chunk);
+    }
     hipStream_t s = c->stream;
     toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
@@ -1749,6 +1850,8 @@ int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* 
 // ---- plumbing ----
 int toyni_malloc(void** d_ptr, size_t bytes) { return d_ptr ? (int)hipMalloc(d_ptr, bytes) : TOYNI_E_NULL; }
 int toyni_free(void* d_ptr) { return (int)hipFree(d_ptr); }
+int toyni_host_alloc(void** h_ptr, size_t bytes) { return h_ptr ? (int)hipHostMalloc(h_ptr, bytes, hipHostMallocPortable) : TOYNI_E_NULL; }
+int toyni_host_free(void* h_ptr) { return (int)hipHostFree(h_ptr); }
 int toyni_memcpy_h2d(void* d, const void* h, size_t bytes) { return (int)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); }
 int toyni_memcpy_d2h(void* h, const void* d, size_t bytes) { return (int)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost); }
 

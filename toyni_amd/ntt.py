@@ -216,6 +216,29 @@ class NttContext:
             self.handle = None
 
 
+class PinnedArray:
+    """count u64 elements of pinned (page-locked) host memory as a numpy array (`.array`), from toyni_host_alloc.  Host-slice
+    calls on it (run_host, ntt_host_multi_gpu) take the pipelined path: upload, kernels and download overlap."""
+
+    def __init__(self, count: int):
+        p = c_void_p()
+        check(lib.toyni_host_alloc(ctypes.byref(p), count * 8), "pinned host allocation failed")
+        self.ptr = p
+        self.array = np.ctypeslib.as_array((ctypes.c_uint64 * count).from_address(p.value))
+
+    def free(self) -> None:
+        if self.ptr:
+            self.array = None
+            lib.toyni_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class GpuBuffer:
     """RAII device buffer of `size` u64 elements (CudaBuffer, src/ntt.rs:153-215)."""
 
