@@ -58,6 +58,7 @@ static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
     }
 }
 
+static bool latency_plan = false;   // "Q1": n = 2^21 / 2^22 through their two-pass latency plan (2048-point three-step shapes)
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
@@ -112,7 +113,7 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
 // BabyBearDomain::fft / ifft on a coset (src/math/domain.rs:85-123) with the scaling fused into the passes
 static void test_coset(int log_n, uint64_t batch, uint32_t shift) {
     NttPlan plan;
-    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    CHECK(build_plan(log_n, plan, latency_plan), "plan %d", log_n);
     const size_t n = (size_t)1 << log_n;
     std::vector<uint64_t> ref(n * batch), want(n * batch);
     orc_fill_splitmix(ref.data(), n * batch, 0xC05E7ull + log_n);
@@ -162,7 +163,7 @@ static void test_field() {
 
 static void test_ntt(int log_n, uint64_t batch, int pattern) {
     NttPlan plan;
-    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    CHECK(build_plan(log_n, plan, latency_plan), "plan %d", log_n);
     const size_t n = (size_t)1 << log_n;
     std::vector<uint64_t> ref(n * batch);
     if (pattern == 0) orc_fill_splitmix(ref.data(), n * batch, 0x70796E69ull + ((uint64_t)log_n << 32));
@@ -272,7 +273,7 @@ static void test_merkle(size_t n, bool salted) {
 // Low-degree extension: compact input (n >> lde_log words per transform), zero padding implied, coset shift fused
 static void test_lde(int log_n, uint64_t batch, int lde_log, uint32_t shift) {
     NttPlan plan;
-    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    CHECK(build_plan(log_n, plan, latency_plan), "plan %d", log_n);
     const uint64_t n = 1ull << log_n, n_in = n >> lde_log;
     std::vector<uint64_t> c64(n_in * batch);
     orc_fill_splitmix(c64.data(), c64.size(), 0x1DE0000ull + (uint64_t)log_n * 64 + (uint64_t)lde_log);
@@ -509,6 +510,10 @@ int main(int argc, char** argv) {
         const char* xb = std::strchr(argv[i], 'x');
         if (argv[i][0] == 'p') {                    // "pN": launches of <= 2^N 32-wide tiles take the three-step shapes from here on (-1: never)
             pass3_max_log_tiles32() = std::atoi(argv[i] + 1);
+            continue;
+        }
+        if (argv[i][0] == 'Q') {
+            latency_plan = argv[i][1] == '1';
             continue;
         }
         if (argv[i][0] == 'w') {                    // "wN": launches of >= 2^N 32-wide tiles take the 64-wide shapes of the 128/256-point passes

@@ -20,7 +20,9 @@ def test_kernel_bodies_match_oracle_on_cpu():
                           "l16x1", "l16x4", "l16x5", "l16x8", "l18x3", "l18x5", "l18x9", "l20x1", "l20x3", "l20x4", "l20x7", "l20x10", "l24x5",
                           "p-1", "16", "18", "20", "s20x2", "l16x5", "l18x3", "l20x5", "l20x10",
                           # wN: launches of >= 2^N 32-wide tiles take the 64-wide shapes of the 128/256/512-point passes; w0 = always
-                          "w0", "13", "14x3", "15", "16", "17x2", "18", "19", "21", "22", "s21x4", "s18x2"], capture_output=True, text=True, timeout=1500)
+                          "w0", "13", "14x3", "15", "16", "17x2", "18", "19", "21", "22", "s21x4", "s18x2",
+                          # Q1: n = 2^21 / 2^22 through their two-pass latency plans (2048-point three-step shapes), plain / coset / LDE
+                          "w10", "p6", "Q1", "21", "22", "l21x5", "l21x3", "l22x5", "l21x11", "Q0"], capture_output=True, text=True, timeout=1800)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout
     import re
@@ -33,7 +35,7 @@ def test_kernel_bodies_are_memory_safe_under_asan_ubsan():
     # the LDS array exactly LDS_WORDS): 2^0..2^11 with ragged batches (2^11 also through the single-sweep LDS kernel in all its
     # workgroup shapes), 2^13 / 2^15 (single-sweep, 32-row tiles), 2^20 (8-wide 1024-point tiles), 2^21 (3 passes)
     exe = entry.build_emu_sanitized()
-    res = subprocess.run([exe, "11", "13", "15", "16", "18", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6", "p-1", "16", "20", "l20x6", "w0", "14", "16", "18", "21"],
+    res = subprocess.run([exe, "11", "13", "15", "16", "18", "20", "21", "s16x2", "s21x8", "l16x5", "l18x2", "l20x6", "p-1", "16", "20", "l20x6", "w0", "14", "16", "18", "21", "w10", "p6", "Q1", "21", "l21x5", "Q0"],
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "ALL OK" in res.stdout

@@ -39,7 +39,11 @@ struct NttPlan {
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
 
-inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES]) {
+// latency = true: the second plan of n = 2^21 / 2^22, two passes (2048-point three-step shapes exist only as 4-wide latency
+// tiles): one launch fewer for a lone transform; streaming launches keep the three-pass split below
+inline bool has_latency_plan(int log_n) { return log_n == 21 || log_n == 22; }
+inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES], bool latency = false) {
+    if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = 11; logm[1] = log_n - 11; logm[2] = 0; return; }
     if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
     if (log_n <= 20) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
     npasses = 3;
@@ -99,11 +103,11 @@ inline void append_two_level(std::vector<uint32_t>& blob, int log_l, uint32_t w,
     }
 }
 
-inline bool build_plan(int log_n, NttPlan& plan) {
+inline bool build_plan(int log_n, NttPlan& plan, bool latency = false) {
     if (log_n < 0 || log_n > MAX_LOG_N) return false;  // cuda/ntt_kernel.cu:217-220
     plan.log_n = log_n;
     int logm[MAX_PASSES];
-    split_passes(log_n, plan.npasses, logm);
+    split_passes(log_n, plan.npasses, logm, latency);
     const uint32_t w_n = bb_root_of_unity_host((uint32_t)log_n);      // cuda/ntt_kernel.cu:222-223
     const uint32_t w_n_inv = bb_pow_host(w_n, (1ull << log_n) - 1);   // omega^(n-1), src/ntt.rs:59
     const uint32_t n_inv = bb_inv_host((uint32_t)((1ull << log_n) % BB_P));  // src/ntt.rs:62
@@ -186,8 +190,11 @@ template <class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
-    if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
+    // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
+    if (log_m == 11 || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m))) {
 #define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false>{}); return true; }
+        TOYNI_PASS3_CASE(KIND_COL, 4, 4, 3)
+        TOYNI_PASS3_CASE(KIND_ROW_T, 4, 4, 3)
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 2)
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 3)
         TOYNI_PASS3_CASE(KIND_COL, 4, 3, 3)
@@ -263,6 +270,7 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
         default: return false;                                                               \
     }
 #define TOYNI_COMMA ,
+    if (log_m == 11) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
     if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
         if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
         if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }

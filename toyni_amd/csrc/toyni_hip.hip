@@ -610,6 +610,11 @@ struct ShiftTable {
 
 struct toyni_ntt_ctx {
     NttPlan plan;
+    // n = 2^21 / 2^22 only: a second, two-pass plan (2048-point three-step shapes) for launches of one or two transforms
+    NttPlan plan_lat;
+    bool has_lat = false;
+    uint32_t* d_fwd_lat = nullptr;
+    uint32_t* d_inv_lat = nullptr;
     uint32_t n = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -870,6 +875,10 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (!ok) return TOYNI_E_INVALID_SIZE;
         return (int)err;
     }
+    // one or two transforms of n = 2^21 / 2^22: the two-pass latency plan (at most 2^pass3_max 32-wide tiles in its first pass)
+    const bool lat = c->has_lat && pass3_max_log_tiles32() >= 0 && (((uint64_t)batch << (c->plan.log_n - 11)) >> 5) <= (1ull << pass3_max_log_tiles32()) &&
+                     (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
+    const NttPlan& plan = lat ? c->plan_lat : c->plan;
     size_t chunk = batch;
     if (c->chunk_elems && c->plan.npasses > 1) {
         chunk = c->chunk_elems / n;
@@ -880,14 +889,14 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         int rc = grow(c, s, (void**)&sc.d_work, &sc.work_words, chunk * n, sizeof(uint32_t));
         if (rc) return rc;
     }
-    const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
+    const uint32_t* tables = lat ? (inverse ? c->d_inv_lat : c->d_fwd_lat) : (inverse ? c->d_inv : c->d_fwd);
     // streaming launches (footprint well beyond the 256 MiB Infinity Cache) take the non-temporal kernels
     const bool nt = lde_log == 0 && (uint64_t)chunk * n * sizeof(uint32_t) >= nt_min_bytes();  // footprint of ONE launch
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
         int pass_index = 0;
-        bool ok = for_each_pass(c->plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb,
+        bool ok = for_each_pass(plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb,
                                 [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
                                     using P = decltype(pass);
                                     constexpr int LZ = decltype(lzc)::value;
@@ -1020,6 +1029,13 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     if ((e = hipMalloc((void**)&c->d_inv, c->plan.inv.size() * sizeof(uint32_t))) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(c->d_fwd, c->plan.fwd.data(), c->plan.fwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(c->d_inv, c->plan.inv.data(), c->plan.inv.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (has_latency_plan(c->plan.log_n) && build_plan(c->plan.log_n, c->plan_lat, true)) {
+        if ((e = hipMalloc((void**)&c->d_fwd_lat, c->plan_lat.fwd.size() * sizeof(uint32_t))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc((void**)&c->d_inv_lat, c->plan_lat.inv.size() * sizeof(uint32_t))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(c->d_fwd_lat, c->plan_lat.fwd.data(), c->plan_lat.fwd.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpy(c->d_inv_lat, c->plan_lat.inv.data(), c->plan_lat.inv.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        c->has_lat = true;
+    }
     *out = c;
     return TOYNI_OK;
 }
@@ -1031,6 +1047,8 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
         (void)hipFree(c->d_fwd);
         (void)hipFree(c->d_inv);
+        (void)hipFree(c->d_fwd_lat);
+        (void)hipFree(c->d_inv_lat);
         (void)hipDeviceSynchronize();  // user streams may still carry this context's kernels
         for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
         for (auto& r : c->retired) (void)hipFree(r.ptr);
