@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the device-resident forward transform for every size 2^4 .. 2^27 at about 1 GiB of data per launch
-sequence (batch = 2^28 / n).  Prints one line per size: passes, ms, elements/s, actual GB/s moved (8 B/element/pass)."""
+sequence (batch = 2^28 / n).  Prints one line per size: passes, ms, elements/s, actual GB/s moved (8 B/element/pass).
+With the measurement build (TOYNI_LIB_OVERRIDE=toyni_amd/lib/libtoyni_hip_tools.so) and SWEEP_PASSES=1: each pass kernel's time."""
 import os
 import sys
 
@@ -36,6 +37,9 @@ def main():
         ms = a.elapsed_time(b) / reps
         print(f"n=2^{log_n:<2d} batch={batch:<9d} passes={ctx.passes} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
               f"{8.0 * ctx.passes * batch * n / ms / 1e9:7.2f} TB/s moved", flush=True)
+        if toyni_amd._lib.HAS_TOOLS and os.environ.get("SWEEP_PASSES"):   # TOYNI_LIB_OVERRIDE=.../libtoyni_hip_tools.so
+            per = ctx.profile_passes(ptr, batch, False, reps=5, stream=stream)
+            print("      per pass: " + "  ".join(f"{t:.4f} ms ({8.0 * batch * n / t / 1e9:.2f} TB/s)" for t in per), flush=True)
         ctx.destroy()
 
 

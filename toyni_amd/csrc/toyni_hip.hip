@@ -891,7 +891,10 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     }
     const uint32_t* tables = lat ? (inverse ? c->d_inv_lat : c->d_fwd_lat) : (inverse ? c->d_inv : c->d_fwd);
     // streaming launches (footprint well beyond the 256 MiB Infinity Cache) take the non-temporal kernels
-    const bool nt = lde_log == 0 && (uint64_t)chunk * n * sizeof(uint32_t) >= nt_min_bytes();  // footprint of ONE launch
+    // -- but not the rows under 256 words: there one load instruction covers a fraction of each 128-byte line it touches and
+    // the following ones come back for the rest, which only the L1 makes cheap (measured at 2^28 elements per launch, plain
+    // vs non-temporal: n = 2^4 351 vs 75 Gel/s, 2^5 331 vs 44, 2^6 545 vs 346, 2^7 633 vs 495; from 2^8 on within +-4 %)
+    const bool nt = lde_log == 0 && plan.log_n >= 8 && (uint64_t)chunk * n * sizeof(uint32_t) >= nt_min_bytes();  // ONE launch's footprint
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
