@@ -244,3 +244,33 @@ def test_pinned_host_memory_takes_the_pipelined_path(ta):
     assert (pin.array == want).all()
     pin.free()
     ctx.destroy()
+
+
+def test_device_calls_can_be_captured_into_a_graph(ta):
+    """A warm context enqueues kernels only (no allocation, no synchronisation), so a caller may capture toyni_ntt_device calls
+    into a HIP graph and replay them: forward 2^20 and coset round trip 2^16, replayed on fresh contents, bit-exact."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for log_n, batch in ((20, 1), (16, 3), (21, 1)):
+        n = 1 << log_n
+        ctx = ta.NttContext(n)
+        buf = torch.zeros(batch * n, dtype=torch.int32, device=dev)
+        out = torch.empty_like(buf)
+        s = torch.cuda.Stream(device=dev)
+        ctx.run_device(buf.data_ptr(), out.data_ptr(), batch, False, stream=s.cuda_stream)      # warm: buffers of this stream exist
+        ctx.run_device(out.data_ptr(), out.data_ptr(), batch, True, stream=s.cuda_stream)
+        ctx.synchronize(s.cuda_stream)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.run_device(buf.data_ptr(), out.data_ptr(), batch, False, stream=s.cuda_stream)
+        for rep in range(3):
+            x = oracle.splitmix(batch * n, 900 + 10 * log_n + rep)
+            buf.copy_(torch.from_numpy(x.astype(np.int32)))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint32).reshape(batch, n)
+            for b in range(batch):
+                assert (got[b] == oracle.ntt(x.reshape(batch, n)[b])).all(), (log_n, rep, b)
+        del g
+        ctx.destroy()

@@ -41,9 +41,11 @@ struct NttPlan {
 
 // latency = true: the second plan of n = 2^21 / 2^22, two passes (2048-point three-step shapes exist only as 4-wide latency
 // tiles): one launch fewer for a lone transform; streaming launches keep the three-pass split below
+// (n = 2^23 / 2^24 as 4096-point three-step passes were built and measured too: 54.6 against 50.7 us and 124 against 88 us for the
+// three-pass plan -- a 4096 x 4 tile is one 1024-thread workgroup per CU with 16-byte row segments; not kept)
 inline bool has_latency_plan(int log_n) { return log_n == 21 || log_n == 22; }
 inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES], bool latency = false) {
-    if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = 11; logm[1] = log_n - 11; logm[2] = 0; return; }
+    if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
     if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
     if (log_n <= 20) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
     npasses = 3;
@@ -174,6 +176,13 @@ inline int& pass3_max_log_tiles32() {
     return v;
 }
 
+// launches that take the two-pass latency plan of n = 2^21 / 2^22 (has_latency_plan): those whose first pass has at most this
+// many (log2) 32-wide tiles' worth of columns
+inline int& lat_max_log_tiles32() {
+    static int v = 7;
+    return v;
+}
+
 // experiment switches (compile time): tile width (log2) of the wide variants of the 128-point and the 512-point passes
 #ifndef TOYNI_WIDE_43
 #define TOYNI_WIDE_43 6
@@ -182,7 +191,7 @@ inline int& pass3_max_log_tiles32() {
 #define TOYNI_WIDE_54 6
 #endif
 inline int& wide_min_log_tiles32() {
-    static int v = 10;
+    static int v = 12;
     return v;
 }
 

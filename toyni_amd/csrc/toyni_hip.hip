@@ -115,15 +115,34 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const Pas
     uint32_t v = blockIdx.x;
     if (v >= ntiles) return;
     uint32_t* lds_tw = lds + P::LDS_WORDS;
-    for (uint32_t j = tid; j < P::TW_WORDS; j += P::T) lds_tw[j] = P::tw_global(a)[j];
+    // the stage table's way into LDS overlaps the first tile's loads: both are issued before either is waited for (a lone
+    // transform is one tile per workgroup, and two memory latencies in a row were a third of such a launch)
+    constexpr uint32_t TW_REGS = (P::TW_WORDS + P::T - 1) / P::T;
+    uint32_t tw_regs[TW_REGS];
+#pragma unroll
+    for (uint32_t k = 0; k < TW_REGS; ++k) {
+        const uint32_t j = tid + k * P::T;
+        tw_regs[k] = j < P::TW_WORDS ? P::tw_global(a)[j] : 0u;
+    }
     const typename P::Uniform uni = P::load_uniform(a);
-    __syncthreads();
+    bool first = true;
     while (true) {
         const typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
         uint32_t x[P::E];
         P::template load_tile<LZ>(a, t, tid, x);
         const typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
         const typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
+        if (first) {
+#pragma unroll
+            for (uint32_t k = 0; k < TW_REGS; ++k) {
+                const uint32_t j = tid + k * P::T;
+                if (j < P::TW_WORDS) lds_tw[j] = tw_regs[k];
+            }
+            TOYNI_SCHED_FENCE();
+            TOYNI_LDS_BARRIER();
+            TOYNI_SCHED_FENCE();
+            first = false;
+        }
         P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw);
         TOYNI_SCHED_FENCE();
         TOYNI_LDS_BARRIER();
@@ -875,8 +894,10 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (!ok) return TOYNI_E_INVALID_SIZE;
         return (int)err;
     }
-    // one or two transforms of n = 2^21 / 2^22: the two-pass latency plan (at most 2^pass3_max 32-wide tiles in its first pass)
-    const bool lat = c->has_lat && pass3_max_log_tiles32() >= 0 && (((uint64_t)batch << (c->plan.log_n - 11)) >> 5) <= (1ull << pass3_max_log_tiles32()) &&
+    // a lone transform (or a few) of n = 2^21 / 2^22: the two-pass latency plan, while its first pass has at most
+    // 2^lat_max_log_tiles32() 32-wide tiles' worth of columns
+    const bool lat = c->has_lat && pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
+                     (((uint64_t)batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32()) &&
                      (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
     const NttPlan& plan = lat ? c->plan_lat : c->plan;
     size_t chunk = batch;
@@ -1020,6 +1041,7 @@ int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     if (!build_plan(ilog2(n), c->plan)) { delete c; return TOYNI_E_INVALID_SIZE; }
     if (const char* env = std::getenv("TOYNI_CHUNK_ELEMS")) c->chunk_elems = (size_t)std::strtoull(env, nullptr, 0);
     if (const char* env = std::getenv("TOYNI_WIDE_TILES")) wide_min_log_tiles32() = std::atoi(env);  // tuning knob (99: never the 64-wide shapes)
+    if (const char* env = std::getenv("TOYNI_LAT_TILES")) lat_max_log_tiles32() = std::atoi(env);  // tuning knob (-1: never the two-pass latency plans)
     if (const char* env = std::getenv("TOYNI_P3_TILES")) pass3_max_log_tiles32() = std::atoi(env);  // tuning knob (-1: never the three-step shapes)
     {
         hipDeviceProp_t prop;
