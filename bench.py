@@ -671,12 +671,14 @@ def main():
         def fri_phase(fused):
             state = b"toyni-stark-v1"
             x0 = 7
+            soff = 0                                                         # salts of the salted layers back to back
             for k in range(17):
                 state = hashlib.sha256(state).digest()                       # squeeze_challenge, src/transcript.rs
                 beta = int.from_bytes(state[:8], "little") % P
                 m = n_l >> k
                 salted = (m // 2) != 16
-                sp = salts_all.data_ptr() if salted else 0
+                sp = salts_all.data_ptr() + 16 * soff if salted else 0
+                soff += m // 2
                 if fused:
                     toyni_amd.prover.fri_fold_commit_device(c_l, lay[k].data_ptr(), lay[k + 1].data_ptr(), m, beta, x0, sp, lvls[k + 1].data_ptr(), stream=stream)
                 else:
@@ -688,6 +690,27 @@ def main():
 
         assert fri_phase(True) == fri_phase(False), "fused and separate FRI rounds disagree"
 
+        # the same 17 rounds through toyni_fri_commit_phase_device: the loop runs inside the library, the transcript stays a callback
+        lay_all = torch.empty(n_l - 16, dtype=torch.int32, device=dev)
+        lvl_all = torch.empty((sum(_tlib.toyni_merkle_total_digests(n_l >> k) for k in range(1, 18)), 32), dtype=torch.uint8, device=dev)
+
+        def fri_phase_one_call():
+            st = {"t": b"toyni-stark-v1"}
+
+            def challenge(_rnd, root, want_beta):
+                if root is not None:
+                    st["t"] += root
+                if not want_beta:
+                    return 0
+                st["t"] = hashlib.sha256(st["t"]).digest()
+                return int.from_bytes(st["t"][:8], "little") % P
+
+            toyni_amd.prover.fri_commit_phase_device(c_l, lay[0].data_ptr(), n_l, 7, 16, salts_all.data_ptr(), challenge, lay_all.data_ptr(),
+                                                     lvl_all.data_ptr(), stream=stream)
+            return st["t"]
+
+        assert fri_phase_one_call() == fri_phase(True), "one-call FRI phase and round-by-round calls disagree"
+
         def wall(fn, reps):
             fn()
             torch.cuda.synchronize()
@@ -698,9 +721,11 @@ def main():
             return (time.perf_counter() - t0w) / reps
 
         extras["fri_phase_protocol_order_2^21"] = {
+            "one_call_ms": wall(fri_phase_one_call, 5) * 1e3,
             "fused_fold_commit_ms": wall(lambda: fri_phase(True), 5) * 1e3, "separate_fold_then_commit_ms": wall(lambda: fri_phase(False), 5) * 1e3,
-            "rounds": 17, "note": "wall time incl. the per-round root read-back and host transcript (beta_{k+1} depends on root_k)"}
-        del lay, lvls, salts_all
+            "rounds": 17, "note": "wall time incl. the per-round root read-back and host transcript (beta_{k+1} depends on root_k); one_call = "
+            "toyni_fri_commit_phase_device (the loop inside the library, the transcript a callback), the others one or two library calls per round"}
+        del lay, lvls, salts_all, lay_all, lvl_all
 
         # ---- BASELINE configs[2]: the whole prover-shaped harness (tests/harness/fib_prover.py) at trace_len 2^16, blowup 32:
         #      every heavy step is a device call of this library (LDE, constraint/quotient, coset INTTs, OOD evaluations, DEEP, 17

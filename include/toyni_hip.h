@@ -225,6 +225,23 @@ int toyni_merkle_commit_host(const uint64_t* h_values, const uint8_t* h_salts, s
  * beta depends on this tree's root (the last 32 bytes of d_levels), so a round is as far as the protocol lets the fusion go. */
 int toyni_fri_fold_commit_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0,
                                  const uint8_t* d_salts, uint8_t* d_levels, void* stream);
+/* The WHOLE fold loop of the commit phase (src/fibonacci.rs:222-245) in one blocking call: rounds of toyni_fri_fold_commit_device
+ * while the layer is longer than final_size (a power of two, >= 1).  The protocol's dependency is kept, not broken: before every
+ * fold the library calls `challenge(user, round, root, &beta)` with the root committed by the previous round (root = NULL in
+ * round 0) -- the caller's Fiat-Shamir transcript absorbs it (absorb_commitment, src/transcript.rs:29-32) and squeezes beta
+ * (squeeze_challenge, :34-40); after the last round it is called once more with beta_out = NULL to absorb the last root.  A
+ * non-zero return of the callback aborts with that code.  Per round only the 32-byte root crosses PCIe.
+ *   d_layer0 : m0 words on the points x0 w_m0^i (the DEEP layer, :205-214); round k folds on x0^(2^k) (the squared domain, :228-231)
+ *   d_salts  : 16 bytes per leaf for every SALTED layer back to back (m0/2 + m0/4 + ... leaves, the final layer excluded:
+ *              build_unsalted_tree, :236-240), or NULL for unsalted trees throughout
+ *   d_layers : out, the folded layers back to back (m0/2 + m0/4 + ... + final_size words)
+ *   d_levels : out, their trees back to back (toyni_merkle_total_digests(m_k) x 32 bytes each, 16-byte aligned)
+ *   h_roots  : out, rounds x 32 bytes (may be NULL); *rounds_out = number of rounds = log2(m0 / final_size)
+ * `stream` carries the kernels; the call returns after the last root has been read back. */
+typedef int (*toyni_fri_challenge_fn)(void* user, unsigned round, const uint8_t* prev_root32, uint32_t* beta_out);
+int toyni_fri_commit_phase_device(toyni_ntt_ctx* ctx, const uint32_t* d_layer0, size_t m0, uint32_t x0, size_t final_size,
+                                  const uint8_t* d_salts, toyni_fri_challenge_fn challenge, void* user, uint32_t* d_layers,
+                                  uint8_t* d_levels, uint8_t* h_roots, unsigned* rounds_out, void* stream);
 /* Constraint and quotient evaluations (src/fibonacci.rs:133-150): with n = N >> log_blowup, g = w_n, T(g x_i) = trace[(i + B) mod N]:
  *   c_i = (T(g^2 x_i) - (T(g x_i) + T(x_i))) (x_i - g^(n-1)) (x_i - g^(n-2)),   q_i = c_i / (x_i^n - 1).
  * d_c_evals may be NULL.  TOYNI_E_ZERO_INVERSE if Z_H vanishes on the coset (shift^n a B-th root of unity). */

@@ -13,7 +13,8 @@ reference's own Lagrange interpolation (O(n^3)) and Horner LDE (O(N d)) are infe
   constraint / quotient  -> toyni_fib_quotient_device          (src/fibonacci.rs:133-150, one kernel)
   OOD evaluations        -> toyni_poly_eval_device             (t_z, t_gz, t_ggz share one read of the coefficients)
   DEEP layer             -> toyni_fib_deep_device              (src/fibonacci.rs:186-198, one inversion per 8 points)
-  FRI round              -> toyni_fri_fold_commit_device       (fold + leaf hashes in one sweep, then the node levels)
+  FRI fold loop          -> toyni_fri_commit_phase_device      (per round: fold + leaf hashes in one sweep, node levels, root to the
+                                                               transcript callback)
   query openings         -> toyni_merkle_open_device           (all ~1 700 paths gathered on the device, ONE copy to the host)
 The only torch arithmetic left is the masking of 140 coefficients.
 
@@ -200,27 +201,40 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     pv.fib_deep_device(ctx_N, trace_lde.data_ptr(), q32.data_ptr(), d32.data_ptr(), 5, COSET_SHIFT, z, [t_z, t_gz, t_ggz, q_z], stream=stream)
     lap("5_deep")
 
-    # ---- 6. FRI: fold + commit, one device call per round (src/fibonacci.rs:200-247) ----
+    # ---- 6. FRI: the whole fold loop in ONE library call (src/fibonacci.rs:200-247); the transcript stays here, behind a callback:
+    #         the library hands over round k's root, gets beta_{k+1} back, and only those 32 bytes cross PCIe per round ----
     layers = [d32]
     trees = [DeviceTree(d32, take_salts(N), stream)]
     commitments = [trees[0].root()]
     tr.absorb(commitments[0])
-    x0 = COSET_SHIFT
-    while layers[-1].numel() > final_size:
-        beta = tr.squeeze_challenge()                              # depends on the previous round's root: rounds cannot be merged
-        cur = layers[-1]
-        m = cur.numel()
-        half = m // 2
-        folded = torch.empty(half, dtype=torch.int32, device=dev)
-        salts = take_salts(half) if half != final_size else None   # the final layer is committed unsalted, :234-238
-        levels = torch.empty((_lib.toyni_merkle_total_digests(half), 32), dtype=torch.uint8, device=dev)
-        pv.fri_fold_commit_device(ctx_N, cur.data_ptr(), folded.data_ptr(), m, beta, x0, salts.data_ptr() if salts is not None else 0,
-                                  levels.data_ptr(), stream=stream)
-        x0 = x0 * x0 % P                                          # xs truncated and squared, src/fibonacci.rs:228-231
+    sizes = []
+    m = N
+    while m > final_size:
+        m //= 2
+        sizes.append(m)
+    layers_all = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
+    digests = [_lib.toyni_merkle_total_digests(h) for h in sizes]
+    levels_all = torch.empty((sum(digests), 32), dtype=torch.uint8, device=dev)
+    salted = [h for h in sizes if h != final_size]                 # the final layer is committed unsalted, :234-238
+    salts_all = take_salts(sum(salted)) if salted else None
+
+    def challenge(_round, root, want_beta):                        # depends on the previous round's root: rounds cannot be merged
+        if root is not None:
+            commitments.append(root)
+            tr.absorb(root)
+        return tr.squeeze_challenge() if want_beta else 0
+
+    pv.fri_commit_phase_device(ctx_N, d32.data_ptr(), N, COSET_SHIFT, final_size, salts_all.data_ptr() if salts_all is not None else 0,
+                               challenge, layers_all.data_ptr(), levels_all.data_ptr(), stream=stream)
+    lo = dlo = slo = 0
+    for h, nd in zip(sizes, digests):
+        folded = layers_all[lo:lo + h]
+        salts = salts_all[slo:slo + h] if h != final_size else None
         layers.append(folded)
-        trees.append(DeviceTree(folded, salts, stream, levels=levels))
-        commitments.append(trees[-1].root())
-        tr.absorb(commitments[-1])
+        trees.append(DeviceTree(folded, salts, stream, levels=levels_all[dlo:dlo + nd]))
+        lo, dlo = lo + h, dlo + nd
+        if h != final_size:
+            slo += h
     final_layer = [int(v) for v in layers[-1].cpu().numpy().view(np.uint32)]
     lap("6_fri_fold_commit")
 

@@ -131,3 +131,81 @@ def test_fold_commit_round(env, log_m, salted):
     ta.merkle_commit_device(out2.data_ptr(), s.data_ptr() if salted else 0, half, lv2.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(out, out2) and torch.equal(lv, lv2)
+
+
+@pytest.mark.parametrize("log_m0,final_size,salted", [(6, 4, True), (10, 1, False), (14, 16, True), (21, 16, True)])
+def test_commit_phase_in_one_call(env, log_m0, final_size, salted):
+    """toyni_fri_commit_phase_device = the fold loop of src/fibonacci.rs:222-245: every layer as the oracle's fri_fold on the squared
+    domain, every tree as build_merkle_tree (the final layer unsalted, :236-240), betas from a transcript that absorbed the previous
+    root (here: SHA-256 chaining as src/transcript.rs:29-40), and the callback sees exactly the committed roots in order."""
+    import hashlib
+    ta, torch, dev = env
+    lib = ta._lib.lib
+    m0 = 1 << log_m0
+    ctx = ta.ntt.get_or_create_ctx(m0)
+    e = oracle.splitmix(m0, 7000 + log_m0)
+    x0 = 7
+    sizes = []
+    m = m0
+    while m > final_size:
+        m //= 2
+        sizes.append(m)
+    rng = np.random.default_rng(log_m0)
+    salts = [rng.integers(0, 256, (h, 16), dtype=np.uint8) for h in sizes[:-1]] if salted else None
+    state = {"t": b"toyni-test", "seen": []}
+
+    def challenge(rnd, root, want_beta):
+        if root is not None:
+            state["seen"].append(root)
+            state["t"] = state["t"] + root                       # absorb_commitment
+        if not want_beta:
+            return 0
+        h = hashlib.sha256(state["t"]).digest()                  # squeeze_challenge: hash, feed back, reduce
+        state["t"] = h
+        return int.from_bytes(h, "little") % P
+
+    te = _dev(torch, dev, e)
+    layers = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
+    total = sum(lib.toyni_merkle_total_digests(h) for h in sizes)
+    levels = torch.zeros((total, 32), dtype=torch.uint8, device=dev)
+    d_salts = torch.from_numpy(np.concatenate(salts)).to(dev) if salted and salts else None
+    roots = ta.prover.fri_commit_phase_device(ctx, te.data_ptr(), m0, x0, final_size, d_salts.data_ptr() if d_salts is not None else 0,
+                                              challenge, layers.data_ptr(), levels.data_ptr())
+    assert len(roots) == len(sizes) and state["seen"] == roots
+    # replay on the CPU with the same transcript
+    got_layers, got_levels = _host(layers), levels.cpu().numpy()
+    t = b"toyni-test"
+    cur, x, lo, dlo = e, x0, 0, 0
+    for k, h in enumerate(sizes):
+        if k:
+            t = t + roots[k - 1]
+        t = hashlib.sha256(t).digest()
+        beta = int.from_bytes(t, "little") % P
+        want = oracle.fri_fold(cur, oracle.domain_elements(2 * h, x), beta)
+        assert (got_layers[lo:lo + h] == want).all(), k
+        folded = got_layers[lo:lo + h]
+        s = salts[k] if salted and k < len(sizes) - 1 else None
+        tree = np.concatenate(oracle.merkle_commit_values(folded, s))
+        nd = lib.toyni_merkle_total_digests(h)
+        assert (got_levels[dlo:dlo + nd] == tree).all(), k
+        assert got_levels[dlo + nd - 1].tobytes() == roots[k]
+        cur, x, lo, dlo = folded, x * x % P, lo + h, dlo + nd
+
+
+def test_commit_phase_reports_a_failing_transcript(env):
+    ta, torch, dev = env
+    ctx = ta.ntt.get_or_create_ctx(64)
+    te = _dev(torch, dev, oracle.splitmix(64, 1))
+    layers = torch.empty(63, dtype=torch.int32, device=dev)
+    levels = torch.zeros((200, 32), dtype=torch.uint8, device=dev)
+
+    def bad(rnd, root, want_beta):
+        if rnd == 2:
+            raise RuntimeError("transcript failure")
+        return 5
+
+    with pytest.raises(RuntimeError, match="transcript failure"):
+        ta.prover.fri_commit_phase_device(ctx, te.data_ptr(), 64, 7, 1, 0, bad, layers.data_ptr(), levels.data_ptr())
+    # a beta outside the field is refused, not reduced silently
+    with pytest.raises(Exception):
+        ta.prover.fri_commit_phase_device(ctx, te.data_ptr(), 64, 7, 1, 0, lambda r, root, w: P, layers.data_ptr(), levels.data_ptr())

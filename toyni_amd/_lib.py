@@ -44,6 +44,9 @@ c_void_p = ctypes.c_void_p
 p_u64 = ctypes.POINTER(ctypes.c_uint64)
 p_u32 = ctypes.POINTER(ctypes.c_uint32)
 
+# toyni_fri_challenge_fn: int (*)(void* user, unsigned round, const uint8_t* prev_root32, uint32_t* beta_out)
+FRI_CHALLENGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32))
+
 # name -> (restype, argtypes); mirrors include/toyni_hip.h line by line
 SIGNATURES = {
     # section 1: the reference's ABI
@@ -97,6 +100,8 @@ SIGNATURES = {
     "toyni_merkle_commit_host": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     # section 3c
     "toyni_fri_fold_commit_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_u32, c_void_p, c_void_p, c_void_p]),
+    "toyni_fri_commit_phase_device": (c_int, [c_void_p, c_void_p, c_size, c_u32, c_size, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, ctypes.POINTER(ctypes.c_uint), c_void_p]),
     "toyni_fib_quotient_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_fib_deep_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_u32, c_void_p, c_void_p]),
     "toyni_poly_eval_device": (c_int, [c_void_p, c_void_p, c_size, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),

@@ -106,6 +106,20 @@ struct SlabGroup {
     uint32_t n = 0;
     size_t m1 = 0, s1 = 0;
     bool rccl_ready = false, host_buffers = false;
+    // registered groups live as long as the process; this runs for a group whose construction failed half way
+    ~SlabGroup() {
+        for (SlabLane& L : lanes) {
+            DeviceGuard guard(L.device);
+            if (L.stream) (void)hipStreamDestroy(L.stream);
+            if (L.ready) (void)hipEventDestroy(L.ready);
+            for (hipStream_t st : L.pull) if (st) (void)hipStreamDestroy(st);
+            for (hipEvent_t ev : L.got) if (ev) (void)hipEventDestroy(ev);
+            if (L.d_xchg) (void)hipFree(L.d_xchg);
+            if (L.d_slab) (void)hipFree(L.d_slab);
+            if (L.d_rows) (void)hipFree(L.d_rows);
+            if (L.d_stage) (void)hipFree(L.d_stage);
+        }
+    }
 };
 
 #define MG_TRY(expr) do { int _rc = (int)(expr); if (_rc) return _rc; } while (0)
@@ -142,8 +156,8 @@ int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
         DeviceGuard guard(L.device);
         MG_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         MG_TRY(hipEventCreateWithFlags(&L.ready, hipEventDisableTiming));
-        L.pull.resize((size_t)ndev);
-        L.got.resize((size_t)ndev);
+        L.pull.assign((size_t)ndev, nullptr);
+        L.got.assign((size_t)ndev, nullptr);
         for (int sidx = 0; sidx < ndev; ++sidx) {
             MG_TRY(hipStreamCreateWithFlags(&L.pull[(size_t)sidx], hipStreamNonBlocking));
             MG_TRY(hipEventCreateWithFlags(&L.got[(size_t)sidx], hipEventDisableTiming));
@@ -185,16 +199,17 @@ int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPt
     if (exchange == TOYNI_EXCHANGE_RCCL) {
         const RcclApi& api = rccl();
         if (api.GroupStart() != 0) return TOYNI_E_RCCL;
-        for (size_t a = 0; a < G; ++a) {
+        bool queued = true;
+        for (size_t a = 0; a < G && queued; ++a) {
             SlabLane& L = g->lanes[a];
             DeviceGuard guard(L.device);      // the communicator's device is current while its calls are queued
-            for (size_t b = 0; b < G; ++b) {  // in stream order on the lane's compute stream: no events needed
-                if (api.Send(send(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;
-                if (api.Recv(recv(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) != 0) return TOYNI_E_RCCL;
+            for (size_t b = 0; b < G && queued; ++b) {  // in stream order on the lane's compute stream: no events needed
+                queued = api.Send(send(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) == 0 &&
+                         api.Recv(recv(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) == 0;
             }
         }
-        if (api.GroupEnd() != 0) return TOYNI_E_RCCL;
-        return TOYNI_OK;
+        const bool closed = api.GroupEnd() == 0;   // the group is closed on the error path too: RCCL's group state is per thread
+        return queued && closed ? TOYNI_OK : TOYNI_E_RCCL;
     }
     for (size_t a = 0; a < G; ++a) {  // every producer marks its outgoing blocks final
         DeviceGuard guard(g->lanes[a].device);

@@ -679,6 +679,7 @@ struct toyni_ntt_ctx {
     bool timing = false;             // toyni_ntt_ctx_timing: bracket every pass launch with events
     std::vector<TimingRec> timing_recs;
 #endif
+    uint8_t* h_root = nullptr;       // pinned 32 bytes: the per-round root read-back of toyni_fri_commit_phase_device
     uint32_t* d_ones = nullptr;      // Montgomery ones: the twiddle-free closing pass of a multi-device inverse (slab_pass)
     std::mutex mu;
 };
@@ -1090,6 +1091,7 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
             }
         }
         (void)hipFree(c->d_ones);
+        if (c->h_root) (void)hipHostFree(c->h_root);
 #ifdef TOYNI_TOOLS
         for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
 #endif
@@ -1280,6 +1282,11 @@ static int host_transform_pipelined(toyni_ntt_ctx* c, uint64_t* h_data, size_t b
         p.cap_elems = chunk * n;
     }
     hipStream_t comp = c->stream;
+    // a failure part way must not return while copies to / from the caller's memory are still in flight
+    struct DrainOnExit {
+        hipStream_t a, b, c;
+        ~DrainOnExit() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); }
+    } drain{p.in, comp, p.out};
     size_t k = 0;
     for (size_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk, elems = nb * n;
@@ -1781,6 +1788,52 @@ int toyni_fri_fold_commit_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint
     int rc = enqueue_fold(c, d_evals, d_out, m, beta, x0, s, d_salts, d_levels);
     if (rc) return rc;
     return enqueue_merkle_upper(d_levels, m / 2, s);
+}
+
+// The fold loop of the commit phase, src/fibonacci.rs:222-245, with the transcript on the caller's side of a callback.
+int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, size_t m0, uint32_t x0, size_t final_size,
+                                  const uint8_t* d_salts, toyni_fri_challenge_fn challenge, void* user, uint32_t* d_layers,
+                                  uint8_t* d_levels, uint8_t* h_roots, unsigned* rounds_out, void* stream) {
+    if (!c || !d_layer0 || !challenge || !d_layers || !d_levels) return TOYNI_E_NULL;
+    if (!is_pow2(m0) || !is_pow2(final_size) || final_size < 1 || m0 > c->n) return TOYNI_E_INVALID_SIZE;
+    if (x0 == 0 || x0 >= BB_P) return TOYNI_E_RANGE;
+    if (((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15)) return TOYNI_E_RANGE;
+    if (rounds_out) *rounds_out = 0;
+    if (m0 <= final_size) return TOYNI_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (!c->h_root) HIPCHK(hipHostMalloc((void**)&c->h_root, 32, hipHostMallocDefault));
+    const uint32_t* cur = d_layer0;
+    uint32_t* out = d_layers;
+    uint8_t* levels = d_levels;
+    const uint8_t* salts = d_salts;
+    uint32_t x = x0;
+    unsigned round = 0;
+    bool have_root = false;
+    for (size_t m = m0; m > final_size; m >>= 1, ++round) {
+        uint32_t beta = 0;
+        int rc = challenge(user, round, have_root ? c->h_root : nullptr, &beta);
+        if (rc) return rc;
+        if (beta >= BB_P) return TOYNI_E_RANGE;
+        const size_t half = m >> 1;
+        const bool last = half == final_size;
+        const size_t digests = toyni_merkle_total_digests(half);
+        if ((rc = enqueue_fold(c, cur, out, m, beta, x, s, last ? nullptr : salts, levels))) return rc;
+        if ((rc = enqueue_merkle_upper(levels, half, s))) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_root, levels + (digests - 1) * 32, 32, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        have_root = true;
+        if (h_roots) std::memcpy(h_roots + (size_t)round * 32, c->h_root, 32);
+        cur = out;
+        out += half;
+        levels += digests * 32;
+        if (salts && !last) salts += half * 16;
+        x = (uint32_t)((uint64_t)x * x % BB_P);   // the squared domain of the next layer, :228-231
+    }
+    if (rounds_out) *rounds_out = round;
+    reclaim_after_sync(c, s);
+    return challenge(user, round, c->h_root, nullptr);   // the transcript absorbs the last commitment too, :242-243
 }
 
 static DomainArgs domain_args(toyni_ntt_ctx* c, unsigned log_m, uint32_t shift) {

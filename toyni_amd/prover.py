@@ -2,6 +2,8 @@
 commitment, constraint / quotient / DEEP evaluation on the LDE coset, polynomial evaluation at the out-of-domain points, and
 Merkle openings.  Mirrors the corresponding lines of `StarkProver::generate_proof` (src/fibonacci.rs:133-150,186-198,222-245,
 366-375) as calls on packed-u32 device pointers; no host arithmetic, no CPU path."""
+import ctypes
+
 import numpy as np
 
 from ._lib import check, lib
@@ -11,6 +13,37 @@ def fri_fold_commit_device(ctx, d_evals: int, d_out: int, m: int, beta: int, x0:
     """fold a layer of m values and commit the folded layer (all tree levels to d_levels) in one call."""
     check(lib.toyni_fri_fold_commit_device(ctx.handle, d_evals, d_out, m, beta, x0, d_salts or None, d_levels, stream or None),
           "GPU fold + commit failed")
+
+
+def fri_commit_phase_device(ctx, d_layer0: int, m0: int, x0: int, final_size: int, d_salts: int, challenge, d_layers: int, d_levels: int,
+                            stream: int = 0):
+    """The fold loop of the commit phase (src/fibonacci.rs:222-245) in one call.  `challenge(round, prev_root: bytes | None,
+    want_beta: bool) -> int` is the caller's transcript: absorb prev_root when it is not None, return the squeezed beta when
+    want_beta (anything otherwise).  Returns the list of roots (bytes), one per round."""
+    from ._lib import FRI_CHALLENGE_FN
+    failure = []
+
+    def _cb(_user, rnd, root_ptr, beta_ptr):
+        try:
+            root = bytes(root_ptr[:32]) if root_ptr else None
+            beta = challenge(int(rnd), root, bool(beta_ptr))
+            if beta_ptr:
+                beta_ptr[0] = int(beta)
+            return 0
+        except Exception as e:  # noqa: BLE001  (an exception must not unwind through the C frames)
+            failure.append(e)
+            return 1
+
+    cb = FRI_CHALLENGE_FN(_cb)
+    rounds = ctypes.c_uint(0)
+    max_rounds = max(0, (m0 // max(final_size, 1)).bit_length() - 1)
+    roots = np.zeros(max(max_rounds, 1) * 32, dtype=np.uint8)
+    rc = lib.toyni_fri_commit_phase_device(ctx.handle, d_layer0, m0, x0, final_size, d_salts or None, ctypes.cast(cb, ctypes.c_void_p), None,
+                                           d_layers, d_levels, roots.ctypes.data, ctypes.byref(rounds), stream or None)
+    if failure:
+        raise failure[0]
+    check(rc, "GPU FRI commit phase failed")
+    return [roots[32 * k:32 * k + 32].tobytes() for k in range(rounds.value)]
 
 
 def fib_quotient_device(ctx, d_trace_lde: int, d_c_evals: int, d_q_evals: int, log_blowup: int, shift: int, stream: int = 0) -> None:
