@@ -5,8 +5,6 @@ costs ~20 % of the headline and nothing functional fails when it happens -- it o
 instantiation of the same pass shape was removed (the inliner then makes different choices).  So the budget is a test."""
 import os
 import re
-import subprocess
-import tempfile
 
 import __graft_entry__ as entry
 
@@ -14,13 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_no_kernel_spills_and_occupancy_targets_hold():
-    src = os.path.join(ROOT, "toyni_amd", "csrc", "toyni_hip.hip")
-    with tempfile.TemporaryDirectory() as tmp:
-        res = subprocess.run([entry._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-c", "-o", os.path.join(tmp, "t.o"), src,
-                              "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900, cwd=tmp)
-    assert res.returncode == 0, res.stderr[-3000:]
-    assert "loop not unrolled" not in res.stderr          # a stage loop that stays rolled indexes registers dynamically -> scratch
-    blocks = re.split(r"remark: [^\n]*Function Name: ", res.stderr)[1:]
+    # the remarks of the build that produced the shipped library (written by build_hip next to it); a stale or missing record
+    # means the library is rebuilt here, so the test always judges the binary that the other tests load
+    entry.build_hip()
+    if not os.path.exists(entry.RESOURCES) or os.path.getmtime(entry.RESOURCES) < os.path.getmtime(entry.LIB) - 5:
+        entry.build_hip(force=True)
+    remarks = open(entry.RESOURCES).read()
+    assert "loop not unrolled" not in remarks             # a stage loop that stays rolled indexes registers dynamically -> scratch
+    blocks = re.split(r"remark: [^\n]*Function Name: ", remarks)[1:]
     seen = 0
     for b in blocks:
         name = b.split(" ")[0]
