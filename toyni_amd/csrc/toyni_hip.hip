@@ -5,6 +5,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -593,7 +595,19 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const Digest* __restr
 // LDS, each round halves it (odd rounds duplicate the last node) and is also written to global memory (the proofs need
 // every level).  Replaces ~log2(m) tiny launches per tree -- the FRI layers of a proof are mostly trees this small.
 constexpr uint32_t MERKLE_TAIL = 1024;
-__global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m) {
+// `notify` (optional): 9 words of pinned host memory -- the root, then a sequence number stored with system-scope release once
+// the root is there.  The host polls that word instead of paying a copy and a stream synchronisation for 32 bytes.
+__device__ inline void merkle_notify(const Digest& root, uint32_t* notify, uint32_t seq) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&root);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __hip_atomic_store(notify + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(notify + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void merkle_notify_kernel(const Digest* __restrict__ root, uint32_t* notify, uint32_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) merkle_notify(*root, notify, seq);
+}
+__global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m,
+                                                          uint32_t* notify, uint32_t seq) {
     __shared__ Digest lvl[MERKLE_TAIL];
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
     __syncthreads();
@@ -616,6 +630,7 @@ __global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restri
         next += up;
         m = up;
     }
+    if (notify && threadIdx.x == 0) merkle_notify(lvl[0], notify, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,7 +694,9 @@ struct toyni_ntt_ctx {
     bool timing = false;             // toyni_ntt_ctx_timing: bracket every pass launch with events
     std::vector<TimingRec> timing_recs;
 #endif
-    uint8_t* h_root = nullptr;       // pinned 32 bytes: the per-round root read-back of toyni_fri_commit_phase_device
+    uint8_t* h_root = nullptr;       // pinned: the per-round root of toyni_fri_commit_phase_device (32 bytes + a sequence word the
+    uint32_t* d_root_notify = nullptr;  // tree's last kernel stores through this device alias of the same memory)
+    uint32_t root_seq = 0;
     uint32_t* d_ones = nullptr;      // Montgomery ones: the twiddle-free closing pass of a multi-device inverse (slab_pass)
     std::mutex mu;
 };
@@ -1724,7 +1741,7 @@ size_t toyni_merkle_total_digests(size_t n) {
 }
 
 // levels above the leaf hashes (already in d_levels[0 .. n))
-static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s);
+static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint32_t* notify = nullptr, uint32_t seq = 0);
 
 int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts, size_t n, uint8_t* d_levels, void* stream) {
     if (!d_values || !d_levels) return TOYNI_E_NULL;
@@ -1736,7 +1753,7 @@ int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts,
     return enqueue_merkle_upper(d_levels, n, s);
 }
 
-static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s) {
+static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint32_t* notify, uint32_t seq) {
     Digest* cur = reinterpret_cast<Digest*>(d_levels);
     size_t m = n;
     while (m > MERKLE_TAIL) {
@@ -1745,7 +1762,8 @@ static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s) {
         cur += m;
         m = up;
     }
-    if (m > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(256), 0, s, (const Digest*)cur, cur + m, (uint32_t)m);
+    if (m > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(256), 0, s, (const Digest*)cur, cur + m, (uint32_t)m, notify, seq);
+    else if (notify) hipLaunchKernelGGL(merkle_notify_kernel, dim3(1), dim3(64), 0, s, (const Digest*)cur, notify, seq);  // a one-leaf tree: the leaf hash is the root
     return (int)hipGetLastError();
 }
 
@@ -1790,6 +1808,15 @@ int toyni_fri_fold_commit_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint
     return enqueue_merkle_upper(d_levels, m / 2, s);
 }
 
+// spin on a word of pinned host memory until the device has stored `want` there (false after `seconds`)
+static bool poll_until(volatile uint32_t* flag, uint32_t want, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (*flag == want) return true;
+        if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    }
+}
+
 // The fold loop of the commit phase, src/fibonacci.rs:222-245, with the transcript on the caller's side of a callback.
 int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, size_t m0, uint32_t x0, size_t final_size,
                                   const uint8_t* d_salts, toyni_fri_challenge_fn challenge, void* user, uint32_t* d_layers,
@@ -1803,7 +1830,12 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
-    if (!c->h_root) HIPCHK(hipHostMalloc((void**)&c->h_root, 32, hipHostMallocDefault));
+    if (!c->h_root) {
+        HIPCHK(hipHostMalloc((void**)&c->h_root, 64, hipHostMallocDefault));   // coherent pinned memory: 32-byte root, then the sequence word
+        std::memset(c->h_root, 0, 64);
+        HIPCHK(hipHostGetDevicePointer((void**)&c->d_root_notify, c->h_root, 0));
+    }
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_root) + 8;
     const uint32_t* cur = d_layer0;
     uint32_t* out = d_layers;
     uint8_t* levels = d_levels;
@@ -1820,9 +1852,15 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
         const bool last = half == final_size;
         const size_t digests = toyni_merkle_total_digests(half);
         if ((rc = enqueue_fold(c, cur, out, m, beta, x, s, last ? nullptr : salts, levels))) return rc;
-        if ((rc = enqueue_merkle_upper(levels, half, s))) return rc;
-        HIPCHK(hipMemcpyAsync(c->h_root, levels + (digests - 1) * 32, 32, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        const uint32_t seq = ++c->root_seq ? c->root_seq : ++c->root_seq;   // never 0
+        if ((rc = enqueue_merkle_upper(levels, half, s, c->d_root_notify, seq))) return rc;
+        // The tree's last kernel writes the root and then `seq` into pinned host memory; everything enqueued before it on `s` has
+        // completed by then (stream order).  Polling costs ~2 us where a 32-byte copy plus a stream synchronisation costs ~16.
+        if (!poll_until(flag, seq, 2.0)) {
+            HIPCHK(hipStreamSynchronize(s));   // never observed; kept so that a lost notification degrades to the slow path
+            if (*flag != seq) HIPCHK(hipMemcpy(c->h_root, levels + (digests - 1) * 32, 32, hipMemcpyDeviceToHost));
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
         have_root = true;
         if (h_roots) std::memcpy(h_roots + (size_t)round * 32, c->h_root, 32);
         cur = out;
@@ -1832,6 +1870,7 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
         x = (uint32_t)((uint64_t)x * x % BB_P);   // the squared domain of the next layer, :228-231
     }
     if (rounds_out) *rounds_out = round;
+    HIPCHK(hipStreamSynchronize(s));   // the call is blocking: the layers and trees are complete when it returns
     reclaim_after_sync(c, s);
     return challenge(user, round, c->h_root, nullptr);   // the transcript absorbs the last commitment too, :242-243
 }
