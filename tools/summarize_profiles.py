@@ -50,6 +50,7 @@ if stats:
     for r in csv.DictReader(open(stats[0])):
         durations[r["Name"]] = float(r["AverageNs"])
 traffic = {"log_n": log_n, "batch_per_gpu": batch, "command": f"python3 bench.py --steps 3 --warmup 1 --log-n {log_n} --batch {batch} --no-extras --no-cpu-baseline",
+           "timing_command": f"python3 bench.py --log-n {log_n} --batch {batch} --no-extras --no-cpu-baseline (default --steps 20 --warmup 3): rocprof_avg_ns",
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "kernels": {}}
 for k, v in allc.items():
     if "ntt_pass_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
