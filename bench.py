@@ -143,6 +143,7 @@ def bench_fourstep(args, dev, rank, world, distributed):
         print(json.dumps({
             "metric": "BabyBear NTT throughput, single transform split over GPUs (%s, one all-to-all)" % ("slab form" if slab else "4-step"), "value": 2 * args.steps * (1 << log_n) / wall,
             "unit": "elements/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
+            "collective_backend": dist.get_backend() if distributed else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"forward+inverse {'slab-form' if slab else '4-step'} NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
