@@ -53,6 +53,29 @@ __global__ void __launch_bounds__(1024) coltile(const uint32_t* __restrict__ in,
     }
 }
 
+// narrow column tiles (C = 4 / 8 / 16 words = 16 / 32 / 64-byte row segments) in the XCD-aware order of Pass3::tile_order: the
+// G = 32 / C tiles that share 128-byte lines go to workgroups p, p + 8, ... (one XCD under round-robin dispatch), so the L2 sees
+// every line once.  E elements per thread, T = C * M / E threads.  PAIRED = 0: tiles in plain order.
+template <int C, int E, int PAIRED>
+__global__ void __launch_bounds__(1024) coltile_narrow(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t ntiles, uint32_t log_s, uint32_t M) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = tid % C, lo = tid / C;
+    const uint32_t rows_per_iter = blockDim.x / C;
+    constexpr uint32_t G = 32 / C;
+    const uint32_t S = 1u << log_s;
+    for (uint32_t v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        uint32_t t = v;
+        if (PAIRED) { const uint32_t s8 = v & (8u * G - 1u); t = (v & ~(8u * G - 1u)) | ((s8 & 7u) * G + (s8 >> 3)); }
+        const uint32_t tiles_per = S / C;
+        const size_t base = (size_t)(t / tiles_per) * M * S + (size_t)(t % tiles_per) * C;
+        uint32_t x[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) x[i] = in[base + (size_t)(lo + i * rows_per_iter) * S + c];
+#pragma unroll
+        for (int i = 0; i < E; ++i) out[base + (size_t)(lo + i * rows_per_iter) * S + c] = x[i] + 1;
+    }
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -96,6 +119,22 @@ int main() {
         printf("coltile C=16 r+w  grid %4d  : %.3f ms  %.2f TB/s\n", grid * 2, ms, 2.0 * n * 4 / ms / 1e9);
         ms = timeit([&] { hipLaunchKernelGGL((coltile<64, 0>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (512 * 64)), log_s, 1024u, 512u); }, 10);
         printf("coltile C=64 M=512 r+w %4d  : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+    }
+    // 4096-point columns of a 4096 x 4096 matrix (n = 2^24, two sweeps): 8- and 4-wide tiles, plain and XCD-paired order
+    {
+        const uint32_t M4 = 4096, ls = 12;
+        for (int grid : {256, 512}) {
+            ms = timeit([&] { hipLaunchKernelGGL((coltile_narrow<8, 32, 0>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (M4 * 8)), ls, M4); }, 10);
+            printf("narrow C=8 M=4096 plain  grid %4d : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+            ms = timeit([&] { hipLaunchKernelGGL((coltile_narrow<8, 32, 1>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (M4 * 8)), ls, M4); }, 10);
+            printf("narrow C=8 M=4096 paired grid %4d : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+            ms = timeit([&] { hipLaunchKernelGGL((coltile_narrow<4, 16, 1>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (M4 * 4)), ls, M4); }, 10);
+            printf("narrow C=4 M=4096 paired grid %4d : %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+            ms = timeit([&] { hipLaunchKernelGGL((coltile_narrow<16, 32, 1>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (2048 * 16)), ls, 2048u); }, 10);
+            printf("narrow C=16 M=2048 paired grid %4d: %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+            ms = timeit([&] { hipLaunchKernelGGL((coltile_narrow<16, 32, 0>), dim3(grid), dim3(1024), 0, 0, in, out, (uint32_t)(n / (2048 * 16)), ls, 2048u); }, 10);
+            printf("narrow C=16 M=2048 plain  grid %4d: %.3f ms  %.2f TB/s\n", grid, ms, 2.0 * n * 4 / ms / 1e9);
+        }
     }
     // padded leading dimension: rows 4 KB + 128 B apart (breaks the power-of-two stride)
     {
