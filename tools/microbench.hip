@@ -79,6 +79,10 @@ DEF_KERNEL(k_mul_hi_u32_u24, uint32_t, t * 8u + j, asm volatile("v_mul_hi_u32_u2
 DEF_KERNEL(k_mad_u32_u24, uint32_t, t * 8u + j, asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x[j]) : "v"(w)))
 DEF_KERNEL(k_mad_u64_u32, uint64_t, (uint64_t)t * 8u + j,
            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[j]) : "v"(w32), "v"((uint32_t)w) : "vcc"))
+DEF_KERNEL(k_lshl_add_u64, uint64_t, (uint64_t)t * 8u + j,
+           asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x[j]) : "v"((uint64_t)w)))
+DEF_KERNEL(k_alignbit, uint32_t, t * 8u + j, asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x[j]) : "v"(w)))
+DEF_KERNEL(k_bitop3, uint32_t, t * 8u + j, asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(x[j]) : "v"(w)))
 DEF_KERNEL(k_pk_add_u16, uint32_t, t * 8u + j, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x[j]) : "v"(w)))
 DEF_KERNEL(k_pk_mul_lo_u16, uint32_t, t * 8u + j, asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x[j]) : "v"(w)))
 DEF_KERNEL(k_pk_mad_u16, uint32_t, t * 8u + j, asm volatile("v_pk_mad_u16 %0, %0, %1, %1" : "+v"(x[j]) : "v"(w)))
@@ -116,6 +120,7 @@ int main(int argc, char** argv) {
         {"v_mov_b32", k_mov_b32, 1, 1},         {"v_cvt_f32_u32", k_cvt_f32_u32, 1, 1},   {"v_mul_lo_u32", k_mul_lo_u32, 1, 1},
         {"v_mul_hi_u32", k_mul_hi_u32, 1, 1},   {"v_mul_u32_u24", k_mul_u32_u24, 1, 1},   {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1, 1},
         {"v_mad_u32_u24", k_mad_u32_u24, 1, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1, 1},   {"v_pk_add_u16", k_pk_add_u16, 1, 2},
+        {"v_lshl_add_u64", k_lshl_add_u64, 1, 1}, {"v_alignbit_b32", k_alignbit, 1, 1},     {"v_bitop3_b32", k_bitop3, 1, 1},
         {"v_pk_mul_lo_u16", k_pk_mul_lo_u16, 1, 2}, {"v_pk_mad_u16", k_pk_mad_u16, 1, 2},
         {"fma_f32+add_u32", k_mix_fma_add, 2, 1}, {"mad_u64+add_u32", k_mix_mad64_add, 2, 1}, {"mont_mul(5 instr)", k_mont_mul, 5, 1},
     };
