@@ -104,6 +104,29 @@ TOYNI_HD void st32(uint32_t* base, uint32_t byte_off, uint32_t v) {
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// Buffer-resource form of the same two accesses: address = resource base (SGPRs) + per-thread byte offset (one VGPR, constant
+// over the registers of a tile) + uniform byte offset (an SGPR) -- no VALU instruction per access, where the pointer form costs one
+// 64-bit VALU add per register (the compiler turns base + i * step into a running VGPR address: 108 v_lshl_add_u64 per tile of the
+// 1024-point column pass, 8 % of its VALU issue).  Offsets are tile-relative (< 2^31).  Measured, alternating A/B against the pointer
+// form (profiles/r02_ab_buffer.txt): stores +0.7 % at 1024 x 2^20, +1.6 % at 4096 x 2^18; loads as well +1.3-2.7 % at 64 x 2^24 and
+// +1.5-2 % at 2^18, but -5.5 % in the 32 x 32 shapes of n = 2^20 (their 32 prefetch loads per thread: the pointer form stays there).
+// -DTOYNI_NO_BUFFER_ADDR: pointer form everywhere (A/B builds).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TOYNI_NO_BUFFER_ADDR)
+#define TOYNI_BUF 1
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+TOYNI_HD BufRsrc buf_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000); }
+template <bool NT = false>
+TOYNI_HD uint32_t ldb32(BufRsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, NT ? 2 : 0);
+}
+template <bool NT = false>
+TOYNI_HD void stb32(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, NT ? 2 : 0);
+}
+#else
+#define TOYNI_BUF 0
+#endif
+
 constexpr uint32_t cx_bitrev(uint32_t x, int bits) {
     uint32_t r = 0;
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1u); x >>= 1; }
@@ -289,18 +312,24 @@ struct Pass {
         const uint32_t off0 = out_offset(a, c, khi) << 2;
         const uint32_t step = (out_offset(a, 0u, 1u << LSH) - out_offset(a, 0u, 0u)) << 2;
         char* base = reinterpret_cast<char*>(t.out);
+#if TOYNI_BUF
+        const BufRsrc ws = buf_rsrc(base);
+#define TOYNI_STORE(B, V) stb32<NT_>(ws, off0, (B) * step, (V))
+#else
+#define TOYNI_STORE(B, V) st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)(B) * step), off0, (V))
+#endif
         if (KIND == KIND_COL) {
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
+                TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
                 if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else if (a.cs_mode == 2u) {  // inverse coset transform: * s^k, k = k0 + b * (register step), running product
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, mont_mul(x[cx_bitrev(b, LB)], tw));
+                TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
                 if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else {
@@ -309,9 +338,10 @@ struct Pass {
             for (uint32_t b = 0; b < NB; ++b) {
                 uint32_t v = x[cx_bitrev(b, LB)];
                 if (scaled) v = mont_mul(v, a.scale);
-                st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step), off0, v);
+                TOYNI_STORE(b, v);
             }
         }
+#undef TOYNI_STORE
     }
 
     // LE bits of radix-2 DIF butterflies on x[0..2^LE), register index bit s <-> sub-transform bit s + SHIFT.
@@ -546,8 +576,17 @@ struct Pass {
         // register i: (uniform base + i * uniform step) + one per-thread offset -> SGPR pointer math, a single VGPR
         const char* base = reinterpret_cast<const char*>(t.in);
         if (live) {
+#if TOYNI_BUF
+            if constexpr (!(LE1 == 5 && LE2 == 5)) {   // measured: the 32 x 32 shapes lose 5.5 % with buffer loads
+                const BufRsrc rs = buf_rsrc(base);
 #pragma unroll
-            for (uint32_t i = I0; i < I1; ++i) x[i] = i < NZ ? ld32<NT_>(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0) : 0u;
+                for (uint32_t i = I0; i < I1; ++i) x[i] = i < NZ ? ldb32<NT_>(rs, off0, i * step) : 0u;
+            } else
+#endif
+            {
+#pragma unroll
+                for (uint32_t i = I0; i < I1; ++i) x[i] = i < NZ ? ld32<NT_>(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0) : 0u;
+            }
         } else {
 #pragma unroll
             for (uint32_t i = I0; i < I1; ++i) x[i] = 0u;
