@@ -23,6 +23,8 @@ def main():
     for log_n in range(lo, hi):
         n = 1 << log_n
         batch = int(os.environ.get("SWEEP_BATCH", TOTAL // n))   # SWEEP_BATCH=1: latency of one transform
+        if batch * n > TOTAL:
+            sys.exit(f"SWEEP_BATCH={batch} x n=2^{log_n} exceeds the {TOTAL}-element buffer of this tool")
         ctx = toyni_amd.NttContext(n)
         f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
         f(); f()

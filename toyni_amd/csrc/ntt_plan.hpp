@@ -5,6 +5,7 @@
 // words) and one two-level table per pass boundary (<= 24 K words), all u32 in Montgomery form.
 // Plain C++ (shared with tests/emu).
 #pragma once
+#include <cstdlib>
 #include <stdint.h>
 #include <type_traits>
 #include <vector>
@@ -44,14 +45,30 @@ struct NttPlan {
 // (n = 2^23 / 2^24 as 4096-point three-step passes were built and measured too: 54.6 against 50.7 us and 124 against 88 us for the
 // three-pass plan -- a 4096 x 4 tile is one 1024-thread workgroup per CU with 16-byte row segments; not kept)
 inline bool has_latency_plan(int log_n) { return log_n == 21 || log_n == 22; }
+// Uneven splits: which pass gets the extra stage.  A column pass also applies the inter-pass twiddle and reads strided; the closing
+// row pass does neither -- so the larger factor goes LAST (experiment switch TOYNI_SPLIT_SMALL_FIRST=0: first, as in round 1).
+inline bool& split_small_first() {
+    static bool v = [] { const char* env = std::getenv("TOYNI_SPLIT_SMALL_FIRST"); return env ? env[0] != '0' : true; }();
+    return v;
+}
 inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES], bool latency = false) {
     if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
     if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
-    if (log_n <= 20) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
+    const bool small_first = split_small_first();
+    if (log_n <= 20) {
+        npasses = 2;
+        const int hi = (log_n + 1) / 2, lo = log_n / 2;
+        const bool swap = small_first && lo >= 6;   // the smallest column shape is 64 points
+        logm[0] = swap ? lo : hi;
+        logm[1] = swap ? hi : lo;
+        logm[2] = 0;
+        return;
+    }
     npasses = 3;
-    logm[0] = (log_n + 2) / 3;
-    logm[1] = (log_n + 1) / 3;
-    logm[2] = log_n / 3;
+    const int a = (log_n + 2) / 3, b = (log_n + 1) / 3, c = log_n / 3;   // a >= b >= c
+    logm[0] = small_first ? c : a;
+    logm[1] = b;
+    logm[2] = small_first ? a : c;
 }
 
 // packed stage table of size-M transform with root w_M: entry [2^t - 1 + x] = w_{2^(t+1)}^x, x < 2^t

@@ -26,6 +26,7 @@ the single-device transform / the oracle on the gathered result.
 The local work goes through a small `LocalOps` interface so that tests can run the SAME exchange logic over gloo
 on CPU tensors (tests/test_dist_cpu.py injects an oracle-backed LocalOps; this package ships only `HipLocalOps`).
 """
+import os
 from typing import Tuple
 
 import torch
@@ -82,7 +83,11 @@ def first_pass_log(log_n: int) -> int:
     """log2 M1 of the single-device plan (toyni_amd/csrc/ntt_plan.hpp split_passes); 0 when the transform is single-pass."""
     if log_n <= 10:
         return 0
-    return (log_n + 1) // 2 if log_n <= 20 else (log_n + 2) // 3
+    small_first = os.environ.get("TOYNI_SPLIT_SMALL_FIRST", "1")[:1] != "0"   # the larger factor goes to the LAST pass (ntt_plan.hpp)
+    if log_n <= 20:
+        hi, lo = (log_n + 1) // 2, log_n // 2
+        return lo if small_first and lo >= 6 else hi
+    return log_n // 3 if small_first else (log_n + 2) // 3
 
 
 def slab_split(log_n: int, world: int) -> Tuple[int, int]:
