@@ -313,8 +313,11 @@ struct Pass {
         const uint32_t step = (out_offset(a, 0u, 1u << LSH) - out_offset(a, 0u, 0u)) << 2;
         char* base = reinterpret_cast<char*>(t.out);
 #if TOYNI_BUF
+        // single-pass kinds keep the pointer form (measured: n = 2^10 loses 17 % with buffer stores, n = 2^4 / 2^5 half their rate with
+        // buffer loads -- profiles/r02_ab_buffer.txt)
         const BufRsrc ws = buf_rsrc(base);
-#define TOYNI_STORE(B, V) stb32<NT_>(ws, off0, (B) * step, (V))
+#define TOYNI_STORE(B, V) do { if constexpr (KIND != KIND_ROW_N) stb32<NT_>(ws, off0, (B) * step, (V)); \
+                               else st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)(B) * step), off0, (V)); } while (0)
 #else
 #define TOYNI_STORE(B, V) st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)(B) * step), off0, (V))
 #endif
@@ -577,7 +580,7 @@ struct Pass {
         const char* base = reinterpret_cast<const char*>(t.in);
         if (live) {
 #if TOYNI_BUF
-            if constexpr (!(LE1 == 5 && LE2 == 5)) {   // measured: the 32 x 32 shapes lose 5.5 % with buffer loads
+            if constexpr (KIND != KIND_ROW_N && !(LE1 == 5 && LE2 == 5)) {   // measured: the 32 x 32 shapes lose 5.5 % with buffer loads
                 const BufRsrc rs = buf_rsrc(base);
 #pragma unroll
                 for (uint32_t i = I0; i < I1; ++i) x[i] = i < NZ ? ldb32<NT_>(rs, off0, i * step) : 0u;
