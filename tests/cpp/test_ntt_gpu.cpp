@@ -1,5 +1,6 @@
 // The reference's three GPU tests (src/ntt.rs:253-311), restated in C++ over the host mirror
 // toyni_amd/csrc/host/toyni_ntt.hpp; the CPU side (`cpu_ntt`) is the oracle.  Run by tests/test_gpu_cpp.py.
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
@@ -95,12 +96,84 @@ static void test_domain_coset_fft_matches_horner() {
     EXPECT(threw, "the mirror has no CPU path");
 }
 
+// toyni_fri_commit_phase_device from compiled code: the fold loop of src/fibonacci.rs:222-245 with the transcript behind a C callback
+// (what a Rust prover binds as an `extern "C" fn` trampoline over its FiatShamirTranscript).  Layers vs orc_fri_fold on the squared
+// domain, trees vs orc_merkle_commit_values, and the callback must see exactly the committed roots, in order.
+extern "C" {
+size_t orc_merkle_total_digests(size_t);
+void orc_merkle_commit_values(uint8_t*, const uint64_t*, const uint8_t*, size_t);
+}
+struct ToyTranscript {
+    uint64_t state = 0x746f796e69ull;
+    std::vector<std::vector<uint8_t>> roots;
+    uint32_t squeeze() { state = state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)((state >> 24) % 2013265921ull); }
+    void absorb(const uint8_t* r) { roots.emplace_back(r, r + 32); for (int i = 0; i < 32; ++i) state = (state ^ r[i]) * 1099511628211ull; }
+};
+static int toy_challenge(void* user, unsigned /*round*/, const uint8_t* prev_root, uint32_t* beta_out) {
+    ToyTranscript* t = static_cast<ToyTranscript*>(user);
+    if (prev_root) t->absorb(prev_root);
+    if (beta_out) *beta_out = t->squeeze();
+    return 0;
+}
+static void test_commit_phase_callback() {
+    if (!ntt::cuda_available()) return;
+    const size_t m0 = 256, final_size = 4;
+    const uint32_t x0 = 7;
+    std::vector<uint32_t> layer0(m0);
+    for (size_t i = 0; i < m0; ++i) layer0[i] = (uint32_t)orc_bb_new(i * 2654435761ull + 99);
+    size_t words = 0, digests = 0;
+    for (size_t m = m0 / 2; m >= final_size; m /= 2) { words += m; digests += orc_merkle_total_digests(m); }
+    uint64_t *d_in = nullptr, *d_layers = nullptr, *d_levels = nullptr;   // cuda_malloc counts u64 words
+    EXPECT(cuda_malloc(&d_in, m0 / 2) == 0 && cuda_malloc(&d_layers, (words + 1) / 2) == 0 && cuda_malloc(&d_levels, digests * 4) == 0, "device allocation");
+    EXPECT(cuda_copy_to_device(d_in, reinterpret_cast<const uint64_t*>(layer0.data()), m0 / 2) == 0, "upload");
+    toyni_ntt_ctx* ctx = nullptr;
+    EXPECT(toyni_ntt_ctx_create((uint32_t)m0, 0, &ctx) == 0, "context");
+    ToyTranscript tr;
+    unsigned rounds = 0;
+    std::vector<uint8_t> roots(32 * 8);
+    const int rc = toyni_fri_commit_phase_device(ctx, reinterpret_cast<const uint32_t*>(d_in), m0, x0, final_size, nullptr, toy_challenge, &tr,
+                                                 reinterpret_cast<uint32_t*>(d_layers), reinterpret_cast<uint8_t*>(d_levels), roots.data(), &rounds, nullptr);
+    EXPECT(rc == 0 && rounds == 6, "commit phase rc=%d rounds=%u", rc, rounds);
+    std::vector<uint32_t> layers(words + 1);
+    std::vector<uint8_t> levels(digests * 32);
+    EXPECT(cuda_copy_from_device(reinterpret_cast<uint64_t*>(layers.data()), d_layers, (words + 1) / 2) == 0, "download layers");
+    EXPECT(cuda_copy_from_device(reinterpret_cast<uint64_t*>(levels.data()), d_levels, digests * 4) == 0, "download trees");
+    EXPECT(tr.roots.size() == rounds, "the callback absorbed %zu roots", tr.roots.size());
+    // replay: same transcript, CPU fold, CPU trees
+    ToyTranscript replay;
+    std::vector<uint64_t> cur(layer0.begin(), layer0.end());
+    uint64_t x = x0;
+    size_t lo = 0, dlo = 0;
+    for (unsigned k = 0; k < rounds; ++k) {
+        if (k) replay.absorb(tr.roots[k - 1].data());
+        const uint32_t beta = replay.squeeze();
+        const size_t m = cur.size(), half = m / 2;
+        std::vector<uint64_t> xs(m), want(half);
+        orc_domain_elements(xs.data(), m, x);
+        orc_fri_fold(want.data(), cur.data(), m, xs.data(), beta);
+        for (size_t i = 0; i < half; ++i) EXPECT(layers[lo + i] == want[i], "round %u layer mismatch at %zu", k, i);
+        const size_t nd = orc_merkle_total_digests(half);
+        std::vector<uint8_t> tree(nd * 32);
+        orc_merkle_commit_values(tree.data(), want.data(), nullptr, half);
+        EXPECT(std::equal(tree.begin(), tree.end(), levels.begin() + dlo * 32), "round %u tree mismatch", k);
+        EXPECT(std::equal(tr.roots[k].begin(), tr.roots[k].end(), tree.end() - 32) && std::equal(roots.begin() + 32 * k, roots.begin() + 32 * k + 32, tree.end() - 32),
+               "round %u root", k);
+        cur = want;
+        x = orc_bb_mul(x, x);
+        lo += half;
+        dlo += nd;
+    }
+    toyni_ntt_ctx_destroy(ctx);
+    cuda_free(d_in); cuda_free(d_layers); cuda_free(d_levels);
+}
+
 int main() {
     test_cuda_available();
     test_cuda_ntt_vs_cpu();
     test_cuda_intt_roundtrip();
     test_buffer_and_fold();
     test_domain_coset_fft_matches_horner();
+    test_commit_phase_callback();
     std::printf("%s\n", fails ? "CPP FAILED" : "CPP OK");
     return fails ? 1 : 0;
 }
