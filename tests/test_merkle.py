@@ -110,7 +110,9 @@ def ta():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,salted", [(1, False), (1, True), (2, True), (3, False), (5, True), (8, False), (1000, True), (1 << 12, True), (1 << 16, False)])
+@pytest.mark.parametrize("n,salted", [(1, False), (1, True), (2, True), (3, False), (5, True), (8, False), (1000, True), (1 << 12, True), (1 << 16, False),
+                                      # ragged sizes above the single-workgroup tail: odd levels inside the two-levels-per-launch kernel
+                                      (2049, False), (4097, True), (5001, False), (9999, True), ((1 << 13) + 3, False), (70001, True), (4098, False), (6146, True)])
 def test_gpu_tree_vs_oracle(ta, n, salted):
     vals = oracle.splitmix(n, 500 + n)
     salts = np.random.default_rng(n).integers(0, 256, (n, 16), dtype=np.uint8) if salted else None
