@@ -908,3 +908,33 @@ def test_fold_ext_and_merkle_golden(ta, golden):
         salts = np.frombuffer(b"".join(bytes.fromhex(s) for s in c["salts_hex"]), dtype=np.uint8).reshape(c["n"], 16)
         assert ta.MerkleTree(c["values"]).root().hex() == c["root_unsalted"]
         assert ta.MerkleTree(c["values"], salts).root().hex() == c["root_salted"]
+
+
+@pytest.mark.parametrize("log_n", [2, 3, 4, 5, 6, 10, 12])
+@pytest.mark.parametrize("misalign_words", [1, 2, 3])
+def test_device_buffers_need_only_word_alignment(ta, log_n, misalign_words):
+    """The packed-u32 device entry points take any 4-byte aligned pointer: the single-step shapes read and write a thread's row
+    with 16-byte accesses, which must not assume more alignment than that.  Ragged batch, out of place and in place, coset inverse."""
+    n, batch = 1 << log_n, 37
+    x = oracle.splitmix(n * batch, 1300 + log_n).astype(np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    pad = 4 * misalign_words
+    a, o = DevBuf(ta, x.nbytes + 16), DevBuf(ta, x.nbytes + 16)
+    try:
+        a.upload(x, offset=pad)
+        ctx.run_device(a.ptr + pad, o.ptr + pad, batch, False)
+        ctx.synchronize()
+        got = o.download(np.uint32, x.size, offset=pad)
+        for b in (0, 1, batch - 1):
+            assert (got[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n].astype(np.uint64))).all(), b
+        ctx.run_device(o.ptr + pad, o.ptr + pad, batch, True)                # inverse in place: back to the input
+        ctx.synchronize()
+        assert (o.download(np.uint32, x.size, offset=pad) == x).all()
+        ctx.run_device(a.ptr + pad, a.ptr + pad, batch, True, shift=7)       # coset inverse: the scaled / twiddled store path
+        ctx.synchronize()
+        got = a.download(np.uint32, x.size, offset=pad)
+        for b in (0, batch - 1):
+            assert (got[b * n:(b + 1) * n] == oracle.domain_ifft(x[b * n:(b + 1) * n].astype(np.uint64), 7)).all(), b
+    finally:
+        a.free()
+        o.free()

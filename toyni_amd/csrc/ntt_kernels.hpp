@@ -104,6 +104,12 @@ TOYNI_HD void st32(uint32_t* base, uint32_t byte_off, uint32_t v) {
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// 16-byte accesses for threads that own CONSECUTIVE words (the single-step shapes: one thread per row of <= 32 points).  The type is
+// declared 4-byte aligned: the rows of a caller's buffer need no more than that, and gfx950 takes unaligned dwordx4 accesses.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#endif
+
 // Buffer-resource form of the same two accesses: address = resource base (SGPRs) + per-thread byte offset (one VGPR, constant
 // over the registers of a tile) + uniform byte offset (an SGPR) -- no VALU instruction per access, where the pointer form costs one
 // 64-bit VALU add per register (the compiler turns base + i * step into a running VGPR address: 108 v_lshl_add_u64 per tile of the
@@ -337,6 +343,23 @@ struct Pass {
             }
         } else {
             const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (!TWO_STEP && KIND == KIND_ROW_N && !NT_ && NB >= 4) {   // the thread's whole row, consecutive words: 16-byte stores
+#pragma unroll
+                for (uint32_t q = 0; q < NB / 4; ++q) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        v[j] = x[cx_bitrev(4 * q + j, LB)];
+                        if (scaled) v[j] = mont_mul(v[j], a.scale);
+                    }
+                    u32x4_a4 w;
+                    w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3];
+                    *reinterpret_cast<u32x4_a4*>(base + off0 + 16u * q) = w;
+                }
+                return;
+            }
+#endif
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
                 uint32_t v = x[cx_bitrev(b, LB)];
@@ -579,6 +602,18 @@ struct Pass {
         // register i: (uniform base + i * uniform step) + one per-thread offset -> SGPR pointer math, a single VGPR
         const char* base = reinterpret_cast<const char*>(t.in);
         if (live) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // one thread per row (single-step shapes): its E1 words are consecutive -- four per load instead of one (a wave's scalar
+            // loads each touch 32 different lines; measured at 2^28 elements: n = 2^4 2.9 -> see profiles/r02_sweep.txt)
+            if constexpr (!TWO_STEP && KIND != KIND_COL && !NT_ && LZ == 0 && I0 == 0 && I1 == E1 && E1 >= 4) {
+#pragma unroll
+                for (uint32_t q = 0; q < E1 / 4; ++q) {
+                    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(base + off0 + 16u * q);
+                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                }
+                return;
+            }
+#endif
 #if TOYNI_BUF
             if constexpr (KIND != KIND_ROW_N && !(LE1 == 5 && LE2 == 5)) {   // measured: the 32 x 32 shapes lose 5.5 % with buffer loads
                 const BufRsrc rs = buf_rsrc(base);
