@@ -73,6 +73,30 @@ def test_slab_multi_gpu_device_layouts(ta, log_n, lanes):
         assert torch.equal(slabs[g], keep[g]), f"slab of lane {g}"
 
 
+def test_slab_multi_gpu_exchange_in_pieces():
+    """TOYNI_SLAB_PIECES = K: the peer-copy exchange issued as K pieces (read once per process, hence a child per value).  8 lanes on
+    device 0, n = 2^21 and 2^16, host form in natural order: forward vs the oracle, inverse back."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, oracle, toyni_amd\n"
+        "for log_n, lanes in ((21, 8), (16, 4), (13, 2)):\n"
+        "    n = 1 << log_n\n"
+        "    x = oracle.splitmix(n, 8800 + log_n)\n"
+        "    v = x.copy()\n"
+        "    toyni_amd.ntt_slab_multi_gpu_host(v, [0] * lanes)\n"
+        "    assert (v == oracle.ntt(x)).all()\n"
+        "    toyni_amd.ntt_slab_multi_gpu_host(v, [0] * lanes, inverse=True)\n"
+        "    assert (v == x).all()\n"
+        "print('PIECES OK')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in ("2", "4", "16"):
+        env = dict(os.environ, TOYNI_SLAB_PIECES=k, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert res.returncode == 0 and "PIECES OK" in res.stdout, k + ": " + res.stdout[-500:] + res.stderr[-2000:]
+
+
 def test_slab_multi_gpu_rccl_group_of_one(ta):
     # the RCCL exchange (dlopen'ed librccl, ncclCommInitAll, grouped send/recv) with the one device of the box: one rank
     n = 1 << 18

@@ -233,11 +233,92 @@ int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPt
     return TOYNI_OK;
 }
 
+// Peer-copy exchange in K pieces (sub-blocks of rq = r / K rows of every destination's row block), so that the relayout and the row
+// transforms of piece q run while pieces q + 1 .. are still on the links (forward), and piece q is on the links while the row
+// transforms of piece q + 1 run (inverse) -- the single-process counterpart of `chunks=K` in toyni_amd/dist.py.  The landing /
+// outgoing buffer d_xchg is piece-major: [K][G][rq][w].  K = TOYNI_SLAB_PIECES, default 1: with all eight lanes on ONE device there
+// is nothing to overlap and the extra launches and copies are pure host-side enqueue cost (2^27: 3.8 ms per forward + inverse at
+// K = 1, 5.9 at 4, 10.3 at 8); whether K > 1 pays on xGMI links has to be measured on a multi-GPU box.
+size_t slab_pieces(size_t r) {
+    static const size_t want = [] { const char* env = std::getenv("TOYNI_SLAB_PIECES"); const long v = env ? std::atol(env) : 1; return (size_t)(v < 1 ? 1 : v); }();
+    size_t k = 1;
+    while (k * 2 <= want && k * 2 <= r) k *= 2;
+    return k;
+}
+
+int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bool inverse) {
+    const size_t G = g->lanes.size();
+    const size_t w = g->s1 / G, r = g->m1 / G, blk = r * w, K = slab_pieces(r), rq = r / K, piece = rq * w;
+    auto copy = [&](SlabLane& D, SlabLane& S, hipStream_t cs, uint32_t* dst, const uint32_t* src) -> int {
+        if (S.device == D.device) return (int)hipMemcpyAsync(dst, src, piece * sizeof(uint32_t), hipMemcpyDeviceToDevice, cs);
+        return (int)hipMemcpyPeerAsync(dst, D.device, src, S.device, piece * sizeof(uint32_t), cs);
+    };
+    if (!inverse) {
+        for (size_t a = 0; a < G; ++a) {  // M1-point column transforms x w_n^(j' k1), in place on the slab; then "my blocks are final"
+            SlabLane& L = g->lanes[a];
+            MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 0, L.stream));
+            DeviceGuard guard(L.device);
+            MG_TRY(hipEventRecord(L.ready, L.stream));
+        }
+        for (size_t q = 0; q < K; ++q) {
+            for (size_t h = 0; h < G; ++h) {  // every destination pulls piece q of its row block from every source, one stream per source
+                SlabLane& D = g->lanes[h];
+                DeviceGuard guard(D.device);
+                for (size_t a = 0; a < G; ++a) {
+                    SlabLane& S = g->lanes[a];
+                    hipStream_t cs = D.pull[a];
+                    if (q == 0) MG_TRY(hipStreamWaitEvent(cs, S.ready, 0));
+                    MG_TRY(copy(D, S, cs, D.d_xchg + q * G * piece + a * piece, d_slabs[a] + h * blk + q * piece));
+                    MG_TRY(hipEventRecord(D.got[a], cs));
+                    MG_TRY(hipStreamWaitEvent(D.stream, D.got[a], 0));
+                }
+            }
+            for (size_t h = 0; h < G; ++h) {  // piece q: pieces -> rows [rq][S1], then the size-S1 transforms over j'
+                SlabLane& L = g->lanes[h];
+                uint32_t* part = d_rows[h] + q * rq * g->s1;
+                MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg + q * G * piece, part, rq, h * r + q * rq, G, 0, L.stream));
+                MG_TRY(toyni_ntt_device(L.row, part, part, rq, 0, L.stream));
+            }
+        }
+    } else {
+        for (size_t q = 0; q < K; ++q) {
+            for (size_t h = 0; h < G; ++h) {  // inverse size-S1 transforms of piece q, then x w_n^-(k1 j') into outgoing pieces
+                SlabLane& L = g->lanes[h];
+                uint32_t* part = d_rows[h] + q * rq * g->s1;
+                MG_TRY(toyni_ntt_device(L.row, part, part, rq, 1, L.stream));
+                MG_TRY(toyni_ntt_slab_relayout_device(L.big, part, L.d_xchg + q * G * piece, rq, h * r + q * rq, G, 1, L.stream));
+                DeviceGuard guard(L.device);
+                MG_TRY(hipEventRecord(L.ready, L.stream));   // re-recorded per piece: the waits below capture this recording
+            }
+            for (size_t a = 0; a < G; ++a) {  // lane a's slab receives rows of block h, piece q, from lane h
+                SlabLane& D = g->lanes[a];
+                DeviceGuard guard(D.device);
+                for (size_t h = 0; h < G; ++h) {
+                    SlabLane& S = g->lanes[h];
+                    hipStream_t cs = D.pull[h];
+                    MG_TRY(hipStreamWaitEvent(cs, S.ready, 0));
+                    MG_TRY(copy(D, S, cs, d_slabs[a] + h * blk + q * piece, S.d_xchg + q * G * piece + a * piece));
+                    if (q + 1 == K) {
+                        MG_TRY(hipEventRecord(D.got[h], cs));
+                        MG_TRY(hipStreamWaitEvent(D.stream, D.got[h], 0));
+                    }
+                }
+            }
+        }
+        for (size_t a = 0; a < G; ++a) {
+            SlabLane& L = g->lanes[a];
+            MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 1, L.stream));  // closing inverse column transforms, 1/M1
+        }
+    }
+    return TOYNI_OK;
+}
+
 int slab_run(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bool inverse, int exchange) {
     const size_t G = g->lanes.size();
     const size_t w = g->s1 / G, r = g->m1 / G, blk = r * w;
-    if (exchange == TOYNI_EXCHANGE_RCCL) MG_TRY(slab_group_rccl(g));
-    else if (exchange != TOYNI_EXCHANGE_PEER_COPY) return TOYNI_E_RANGE;
+    if (exchange == TOYNI_EXCHANGE_PEER_COPY) return slab_run_pieces(g, d_slabs, d_rows, inverse);
+    if (exchange != TOYNI_EXCHANGE_RCCL) return TOYNI_E_RANGE;
+    MG_TRY(slab_group_rccl(g));
     if (!inverse) {
         for (size_t a = 0; a < G; ++a) {  // M1-point column transforms x w_n^(j' k1), in place on the slab
             SlabLane& L = g->lanes[a];
