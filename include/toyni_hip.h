@@ -88,7 +88,8 @@ int toyni_ntt_host_multi_gpu(const int* devices, int ndev, uint32_t n, uint64_t*
 
 /* Device-resident, packed u32, in place (d_in == d_out) or out of place.  Enqueued on `stream`
  * (a hipStream_t; NULL = HIP's default stream, as everywhere in HIP) and NOT synchronised: this is the
- * entry point the roofline numbers are measured on.  batch transforms are contiguous (stride n).
+ * entry point the roofline numbers are measured on.  batch transforms are contiguous (stride n); the pointers need
+ * 4-byte alignment only; elements are canonical residues (< p), outputs are canonical.
  * Any number of streams per context (intermediates are per stream, see "Threading and streams" above). */
 int toyni_ntt_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, int inverse, void* stream);
 
@@ -160,7 +161,9 @@ int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uin
  * landing buffers cached per (device list, n).  `exchange` selects how the one exchange step moves its G x G blocks:
  *   TOYNI_EXCHANGE_PEER_COPY  every destination pulls its blocks with hipMemcpyPeerAsync (xGMI), one copy stream per
  *                             source so that all incoming links are busy at once; the only form that accepts a device
- *                             listed more than once (lanes on one device: the copy is then device-local)
+ *                             listed more than once (lanes on one device: the copy is then device-local).  The environment
+ *                             variable TOYNI_SLAB_PIECES = K (power of two, default 1) issues the exchange as K pieces of every
+ *                             row block, so that the work on piece q overlaps the transfer of the pieces after it
  *   TOYNI_EXCHANGE_RCCL       one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd over ncclCommInitAll
  *                             communicators; librccl is loaded on first use (dlopen), TOYNI_E_NO_RCCL if it is absent
  * Both entry points block until the transform is complete on every device.
