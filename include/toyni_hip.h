@@ -233,7 +233,8 @@ int toyni_fri_fold_commit_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, ui
  * fold the library calls `challenge(user, round, root, &beta)` with the root committed by the previous round (root = NULL in
  * round 0) -- the caller's Fiat-Shamir transcript absorbs it (absorb_commitment, src/transcript.rs:29-32) and squeezes beta
  * (squeeze_challenge, :34-40); after the last round it is called once more with beta_out = NULL to absorb the last root.  A
- * non-zero return of the callback aborts with that code.  Per round only the 32-byte root crosses PCIe.
+ * non-zero return of the callback aborts with that code (after the stream has drained).  The callback runs on the calling thread
+ * with the context locked: it must not call entry points on the same context.  Per round only the 32-byte root crosses PCIe.
  *   d_layer0 : m0 words on the points x0 w_m0^i (the DEEP layer, :205-214); round k folds on x0^(2^k) (the squared domain, :228-231)
  *   d_salts  : 16 bytes per leaf for every SALTED layer back to back (m0/2 + m0/4 + ... leaves, the final layer excluded:
  *              build_unsalted_tree, :236-240), or NULL for unsalted trees throughout

@@ -1813,6 +1813,9 @@ static bool poll_until(volatile uint32_t* flag, uint32_t want, double seconds) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; ++spins) {
         if (*flag == want) return true;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
         if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
     }
 }
@@ -1836,6 +1839,9 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
         HIPCHK(hipHostGetDevicePointer((void**)&c->d_root_notify, c->h_root, 0));
     }
     volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_root) + 8;
+    // the call is blocking on EVERY path: a callback that fails, or an error half way, must not leave kernels running on buffers the
+    // caller is about to release
+    struct DrainOnExit { hipStream_t st; ~DrainOnExit() { (void)hipStreamSynchronize(st); } } drain{s};
     const uint32_t* cur = d_layer0;
     uint32_t* out = d_layers;
     uint8_t* levels = d_levels;
