@@ -36,7 +36,9 @@ mod gpu {
     // &mut [BabyBear] is handed over as *mut u64 (same guarantee the reference asserts at src/ntt.rs:115-116)
     const _: () = assert!(size_of::<BabyBear>() == size_of::<u64>() && align_of::<BabyBear>() == align_of::<u64>());
 
-    fn describe(what: &str, status: c_int) -> String {
+    /// Status of a C-ABI call as the `Err(String)` the reference builds from `cuda_get_error_string` (src/ntt.rs:163-166).
+    /// `pub(crate)`: the optional bindings of INTEGRATION.md section 3 (fold, LDE) live in other modules of the crate.
+    pub(crate) fn describe(what: &str, status: c_int) -> String {
         let msg = unsafe { CStr::from_ptr(toyni_error_string(status)) }.to_string_lossy().into_owned();
         format!("{what}: {msg}")
     }
@@ -45,7 +47,9 @@ mod gpu {
     unsafe impl Send for Ctx {}
 
     /// Per-size contexts live for the whole process, like the reference's cache (src/ntt.rs:128-141).
-    fn context(n: usize) -> Result<*mut c_void, String> {
+    /// `pub(crate)` and re-exported as `crate::ntt::context`: `BabyBearDomain` hands the pointer to the optional entry points
+    /// of INTEGRATION.md section 3 (`toyni_lde_host`, `toyni_coset_ntt_host`, ...).  The context locks itself on the C side.
+    pub(crate) fn context(n: usize) -> Result<*mut c_void, String> {
         static CACHE: OnceLock<Mutex<HashMap<usize, Ctx>>> = OnceLock::new();
         let mut map = CACHE.get_or_init(Default::default).lock().unwrap();
         if let Some(c) = map.get(&n) {
@@ -134,6 +138,8 @@ mod gpu {
 
 #[cfg(all(feature = "hip", has_hip))]
 pub use gpu::{gpu_available, intt_gpu, ntt_gpu, GpuBuffer};
+#[cfg(all(feature = "hip", has_hip))]
+pub(crate) use gpu::{context, describe};
 // the reference's public names (src/ntt.rs:314-315)
 #[cfg(all(feature = "hip", has_hip))]
 pub use gpu::{gpu_available as cuda_available, intt_gpu as intt_cuda, ntt_gpu as ntt_cuda, GpuBuffer as CudaBuffer};
@@ -153,6 +159,34 @@ mod gpu_absent {
     pub fn intt_gpu(_: &mut [BabyBear]) -> Result<(), String> {
         Err("GPU not available".to_string())
     }
+    pub(crate) fn context(_: usize) -> Result<*mut std::ffi::c_void, String> {
+        Err("GPU not available".to_string())
+    }
+    pub(crate) fn describe(what: &str, status: std::ffi::c_int) -> String {
+        format!("{what}: status {status} (built without the HIP backend)")
+    }
+
+    /// Same public surface as the real buffer (reference: CudaBuffer, src/ntt.rs:153-215); `new` always fails, so no value
+    /// of this type ever exists and the other methods are unreachable -- they are here so that users of `CudaBuffer` compile.
+    pub struct GpuBuffer {
+        never: std::convert::Infallible,
+    }
+    impl GpuBuffer {
+        pub fn new(_len: usize) -> Result<Self, String> {
+            Err("GPU not available".to_string())
+        }
+        pub fn copy_from_host(&mut self, _data: &[u64]) -> Result<(), String> {
+            match self.never {}
+        }
+        pub fn copy_to_host(&self, _data: &mut [u64]) -> Result<(), String> {
+            match self.never {}
+        }
+        pub fn as_ptr(&self) -> *mut u64 {
+            match self.never {}
+        }
+    }
 }
 #[cfg(all(feature = "hip", not(has_hip)))]
-pub use gpu_absent::{gpu_available, gpu_available as cuda_available, intt_gpu, intt_gpu as intt_cuda, ntt_gpu, ntt_gpu as ntt_cuda};
+pub use gpu_absent::{gpu_available, gpu_available as cuda_available, intt_gpu, intt_gpu as intt_cuda, ntt_gpu, ntt_gpu as ntt_cuda, GpuBuffer, GpuBuffer as CudaBuffer};
+#[cfg(all(feature = "hip", not(has_hip)))]
+pub(crate) use gpu_absent::{context, describe};

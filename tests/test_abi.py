@@ -115,3 +115,45 @@ def test_rust_and_integration_bindings_match_the_header():
             assert arity == protos[name], f"{path}: {name} takes {arity} arguments, the header says {protos[name]}"
             checked += 1
     assert checked >= 15
+
+
+def _rust_exports(cfg_marker):
+    """Names `rust/src/ntt_gpu.rs` re-exports at file scope (i.e. as `crate::ntt::<name>` once pasted into src/ntt.rs) under the
+    `#[cfg(...)]` line containing `cfg_marker`, and the names the module they come from really defines as pub / pub(crate)."""
+    text = open(os.path.join(ROOT, "rust", "src", "ntt_gpu.rs")).read()
+    exported, defined = set(), set()
+    for m in re.finditer(r"#\[cfg\(([^\]]*)\)\]\s*\n(pub(?:\(crate\))? use (\w+)::\{([^}]*)\};)", text):
+        if m.group(1).replace(" ", "") != cfg_marker.replace(" ", ""):
+            continue
+        module = m.group(3)
+        body = re.search(r"mod %s \{(.*?)\n\}\n" % module, text, flags=re.S).group(1)
+        for item in m.group(4).split(","):
+            parts = item.split(" as ")
+            src_name, out_name = parts[0].strip(), parts[-1].strip()
+            assert re.search(r"pub(?:\(crate\))? (?:fn|struct) %s\b" % src_name, body), f"{module}::{src_name} is re-exported but not pub in the module"
+            exported.add(out_name)
+        defined |= set(re.findall(r"pub(?:\(crate\))? (?:fn|struct) (\w+)", body))
+    return exported
+
+
+def test_integration_sketches_only_use_names_the_rust_module_exports():
+    """INTEGRATION.md's sketches called `crate::ntt::context`, which was private.  Without rustc, check the
+    next best thing: every `crate::ntt::<name>` that INTEGRATION.md uses and every public name of the reference's GPU surface
+    (src/ntt.rs:314-315 + CudaBuffer) is exported by rust/src/ntt_gpu.rs both with hipcc (`has_hip`) and in the stub build."""
+    used = set(re.findall(r"crate::ntt::(\w+)", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert {"context", "gpu_available"} <= used
+    reference_surface = {"cuda_available", "ntt_cuda", "intt_cuda", "CudaBuffer"}
+    neutral = {"gpu_available", "ntt_gpu", "intt_gpu", "GpuBuffer"}
+    for cfg in ('all(feature = "hip", has_hip)', 'all(feature = "hip", not(has_hip))'):
+        exported = _rust_exports(cfg)
+        missing = (used | reference_surface | neutral) - exported
+        assert not missing, f"rust/src/ntt_gpu.rs under cfg({cfg}) does not export {sorted(missing)}"
+    # the stub's GpuBuffer has the real one's methods (a user of CudaBuffer must compile without hipcc)
+    text = open(os.path.join(ROOT, "rust", "src", "ntt_gpu.rs")).read()
+    real = re.search(r"mod gpu \{(.*?)\n\}\n", text, flags=re.S).group(1)
+    stub = re.search(r"mod gpu_absent \{(.*?)\n\}\n", text, flags=re.S).group(1)
+    methods = lambda body: set(re.findall(r"pub fn (\w+)\(", body[body.index("impl GpuBuffer"):]))
+    assert methods(real) == methods(stub) == {"new", "copy_from_host", "copy_to_host", "as_ptr"}
+    # and INTEGRATION.md says which feature the reference's own call sites need
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "--features cuda" in integ and '`--features hip` alone' in integ
