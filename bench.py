@@ -31,7 +31,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU (weak scaling) / in the whole job (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (DEFAULT; the driver's contract): --batch transforms on EVERY GPU.  strong: BASELINE configs[3] as written "
+                         "(SURVEY 8(d) C4): --batch transforms in the whole job, batch/N per GPU (ranks < batch mod N take one more)")
     ap.add_argument("--chunk-elems", type=int, default=-1, help="override the context's batch chunking (-1: library default)")
     ap.add_argument("--no-extras", action="store_true", help="skip single-transform / fold / host-path side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,7 +215,27 @@ def bench_slab_single_process(args):
         step()                                   # the entry point blocks until every lane is done
     wall = time.perf_counter() - t0
     assert all(torch.equal(a, b) for a, b in zip(slabs, keep)), "round trip changed the data"
+    # the forward half against the single-device transform (a round trip alone is the identity for many wrong exchanges): gather the
+    # input in natural order, transform it on device 0 alone, compare every lane's row block
+    verified = None
+    if log_n <= 27:
+        d0 = torch.device("cuda", devices[0])
+        nat = torch.empty(n, dtype=torch.int32, device=d0)
+        for g in range(lanes):
+            nat[tdist.slab_input_index(log_n, lanes, g).to(d0).reshape(-1)] = keep[g].to(d0)
+        one = toyni_amd.NttContext(n, device=devices[0])
+        one.run_device(nat.data_ptr(), nat.data_ptr(), 1, False, stream=torch.cuda.current_stream(d0).cuda_stream)
+        torch.cuda.synchronize(d0)
+        toyni_amd.ntt_slab_multi_gpu_device(n, devices, sp, rp, False, exchange)
+        verified = all(torch.equal(rows[h].to(d0), nat[tdist.slab_output_index(log_n, lanes, h).to(d0).reshape(-1)]) for h in range(lanes))
+        assert verified, "multi-device forward transform differs from the single-device transform"
+        del nat
+    pci = {}
+    for d in sorted(set(devices)):
+        pr = torch.cuda.get_device_properties(d)
+        pci[d] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0) & 0xFF, getattr(pr, "pci_device_id", 0) & 0xFF)
     print(json.dumps({
+        "exchange_verified": verified, "devices": [{"lane": g, "device": d, "pci": pci[d]} for g, d in enumerate(devices)],
         "metric": "BabyBear NTT throughput, single transform split over GPUs from one process (slab form, one exchange)",
         "value": 2 * args.steps * n / wall, "unit": "elements/s", "n_gpus": len(set(devices)), "lanes": lanes, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -223,18 +246,35 @@ def bench_slab_single_process(args):
         "roofline": None, "cpu_baseline": None}))
 
 
+def shard_batch(total, world, rank, scaling):
+    """Transforms of the batch workload that `rank` runs per direction.  weak (the driver's contract, default): --batch on every GPU.
+    strong (BASELINE configs[3] as written): --batch in the whole job, contiguous shards, no collective."""
+    if scaling == "weak":
+        return total
+    return total // world + (1 if rank < total % world else 0)
+
+
 def probe_ranks(args):
-    """What `--gpus N` starts, checked without a GPU: every rank joins a gloo group and adds 1; rank 0 prints the count."""
+    """What `--gpus N` starts, checked without a GPU: every rank joins a gloo group, adds 1 and reports the shard of the batch
+    it would run (the same shard_batch() call the real body makes); rank 0 prints the count and the per-rank table."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     if world > 1:
         dist.init_process_group("gloo")
     t = torch.ones(1, dtype=torch.int64)
+    mine = torch.tensor([rank, shard_batch(args.batch, world, rank, args.scaling)], dtype=torch.int64)
+    table = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_reduce(t)
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(json.dumps({"probe": True, "n_gpus": world, "ranks_counted": int(t.item()), "requested_gpus": args.gpus}))
+        dist.all_gather(table, mine)
+    else:
+        table = [mine]
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "ranks_counted": int(t.item()), "requested_gpus": args.gpus, "scaling": args.scaling,
+                          "ranks": [{"rank": int(r[0]), "transforms_per_step": 2 * int(r[1])} for r in table],
+                          "batch_total": sum(int(r[1]) for r in table)}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -362,7 +402,9 @@ def main():
         return bench_fourstep(args, dev, rank, world, distributed)
 
     n = 1 << args.log_n
-    batch = args.batch
+    # weak: every rank runs --batch transforms.  strong: --batch is the job's total, sharded contiguously (no collective either way)
+    batch = shard_batch(args.batch, world, rank, args.scaling)
+    assert batch >= 1, f"--scaling strong: {args.batch} transforms cannot be sharded over {world} ranks"
     ctx = toyni_amd.NttContext(n, device=dev.index)
     if args.chunk_elems >= 0:
         ctx.set_chunk(args.chunk_elems)
@@ -437,7 +479,27 @@ def main():
     if distributed:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     wall_max = float(el.item())
-    transforms = 2 * batch * args.steps * world
+    # Which device did every rank really run on?  (rank, device ordinal, PCI domain / bus / device, its transforms, its wall time):
+    # rank 0 checks that N ranks sat on N different GPUs (under RCCL; the gloo rehearsal shares devices on purpose) and prints the
+    # per-rank step times next to the maximum that `value` is computed from.
+    prop = torch.cuda.get_device_properties(dev)
+    mine = torch.tensor([rank, dev.index, getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
+                         batch, int(wall * 1e9)], dtype=torch.int64, device=coll_dev)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    if distributed:
+        dist.all_gather(table, mine)
+    else:
+        table = [mine]
+    ranks_table = [{"rank": int(t[0]), "device": int(t[1]), "pci": "%04x:%02x:%02x" % (int(t[2]), int(t[3]) & 0xFF, int(t[4]) & 0xFF),
+                    "transforms_per_step": 2 * int(t[5]), "ms_per_step": int(t[6]) / 1e6 / args.steps} for t in table]
+    if rank == 0 and distributed:
+        print("rank  device  pci           transforms/step  ms/step", file=sys.stderr)
+        for r in ranks_table:
+            print("%4d  %6d  %-12s  %15d  %.3f" % (r["rank"], r["device"], r["pci"], r["transforms_per_step"], r["ms_per_step"]), file=sys.stderr)
+        if backend == "nccl":
+            assert len({r["pci"] for r in ranks_table}) == world, f"{world} ranks share GPUs: {ranks_table}"
+    total_batch = sum(r["transforms_per_step"] for r in ranks_table) // 2
+    transforms = 2 * total_batch * args.steps
     value = transforms * n / wall_max
 
     out = None
@@ -446,14 +508,17 @@ def main():
             "metric": "BabyBear NTT throughput (forward+inverse, device-resident)", "value": value, "unit": "elements/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1, "collective_backend": backend if distributed else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over a batch of {batch} transforms per GPU "
-                            f"(configs[3] repeated-prover batch), in place, inputs resident in HBM",
-                "log_n": args.log_n, "batch_per_gpu": batch, "passes_per_transform": ctx.passes,
+                "workload": (f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over a batch of {batch} transforms per GPU "
+                             f"(configs[3] repeated-prover batch), in place, inputs resident in HBM") if args.scaling == "weak" else
+                            (f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over {total_batch} transforms in the whole job, "
+                             f"{total_batch // world}{'+1' if total_batch % world else ''} per GPU (configs[3] as written: SURVEY 8(d) C4), in place, inputs resident in HBM"),
+                "log_n": args.log_n, "batch_per_gpu": batch, "batch_total": total_batch, "passes_per_transform": ctx.passes,
                 "parallelism": f"batch-sharded x{world}, no collective",
             },
             "gpu_event_ms_per_step": gpu_s / args.steps * 1e3,
+            "ranks": ranks_table,
         }
 
     # ---- roofline of the dominant kernel: per-pass launch durations, HIP events on the launch stream ----

@@ -38,6 +38,10 @@ extern "C" {
 #define TOYNI_E_RANGE 10006          /* argument out of range (layer larger than the context's domain, ...) */
 #define TOYNI_E_NO_RCCL 10007        /* the RCCL exchange was requested and librccl could not be loaded */
 #define TOYNI_E_RCCL 10008           /* an RCCL call failed */
+#define TOYNI_E_NO_PEER_ACCESS 10009 /* two devices of a multi-device group cannot access each other directly (hipDeviceCanAccessPeer);
+                                      * TOYNI_ALLOW_STAGED_PEER=1 accepts host-staged copies instead */
+#define TOYNI_E_REENTRANT 10011      /* an entry point was called on a context from inside that context's transcript callback */
+#define TOYNI_E_SELF_CHECK 10010     /* the first-use check of a multi-device group disagreed with the single-device transform */
 
 typedef struct toyni_ntt_ctx toyni_ntt_ctx;
 
@@ -146,6 +150,7 @@ int toyni_fourstep_twiddle_device(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t r
  * cols_local and rows_local are powers of two, cols_local >= 32.  (src/ntt.rs:11-81 has no multi-device form: values
  * are pinned by the single-device transform and the oracle on the gathered result.) */
 size_t toyni_ntt_ctx_first_pass_points(const toyni_ntt_ctx* ctx);
+size_t toyni_first_pass_points(uint32_t n);   /* the same from n alone: no context, no device (0: n <= 1024 or not a valid size) */
 /* in place on the slab.  inverse = 0: M1-point column transforms times w_n^((col_base + c) k1);
  * inverse = 1: the closing inverse column transforms, scaled by 1/M1 (col_base is not used: the twiddle was applied
  * by the relayout on the other side of the exchange) */
@@ -166,7 +171,11 @@ int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uin
  *                             row block, so that the work on piece q overlaps the transfer of the pieces after it
  *   TOYNI_EXCHANGE_RCCL       one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd over ncclCommInitAll
  *                             communicators; librccl is loaded on first use (dlopen), TOYNI_E_NO_RCCL if it is absent
- * Both entry points block until the transform is complete on every device.
+ * Both entry points block until the transform is complete on every device -- on error paths too: no stream of the group still
+ * touches the caller's buffers when they return.  Peer access between the listed devices is checked (TOYNI_E_NO_PEER_ACCESS), and the
+ * first call on a device list that spans more than one device runs one n = 2^18 transform through the same exchange and compares
+ * it with the single-device result (TOYNI_E_SELF_CHECK on a mismatch; a few ms, once per device list and exchange kind).
+ * TOYNI_VERBOSE=1 prints the lane -> device / PCI bus table and the self-check's verdict to stderr.
  * _device: d_slabs[g] = device g's [M1][S1/G] column slab, d_rows[g] = its [M1/G][S1] row block (layouts of 2b, packed u32,
  *          resident on devices[g]).  forward: slabs in (OVERWRITTEN), rows out; inverse: rows in (OVERWRITTEN), slabs out.
  * _host:   n u64 elements in natural order, in place (x -> X or X -> x); every lane uploads / downloads its own strided share. */
@@ -234,7 +243,8 @@ int toyni_fri_fold_commit_device(toyni_ntt_ctx* ctx, const uint32_t* d_evals, ui
  * round 0) -- the caller's Fiat-Shamir transcript absorbs it (absorb_commitment, src/transcript.rs:29-32) and squeezes beta
  * (squeeze_challenge, :34-40); after the last round it is called once more with beta_out = NULL to absorb the last root.  A
  * non-zero return of the callback aborts with that code (after the stream has drained).  The callback runs on the calling thread
- * with the context locked: it must not call entry points on the same context.  Per round only the 32-byte root crosses PCIe.
+ * with the context locked: entry points on the SAME context return TOYNI_E_REENTRANT from inside it (other contexts are fine).
+ * Per round only the 32-byte root crosses PCIe.
  *   d_layer0 : m0 words on the points x0 w_m0^i (the DEEP layer, :205-214); round k folds on x0^(2^k) (the squared domain, :228-231)
  *   d_salts  : 16 bytes per leaf for every SALTED layer back to back (m0/2 + m0/4 + ... leaves, the final layer excluded:
  *              build_unsalted_tree, :236-240), or NULL for unsalted trees throughout

@@ -27,6 +27,14 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t batch,
 int toyni_ntt_ctx_timing(toyni_ntt_ctx* ctx, int enable);
 int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* ctx, float* ms_sum, uint32_t* launches);
 
+/* Fault injection into the multi-device forms (tests only; csrc/multi_gpu.hpp): bit 0 = every pair of different lanes is treated
+ * as two devices without peer access (group creation must fail with TOYNI_E_NO_PEER_ACCESS); bit 1 = the first-use self-check
+ * also runs for groups whose lanes all sit on one device; bit 2 = that self-check sees one corrupted word (must fail with
+ * TOYNI_E_SELF_CHECK).  0 restores normal behaviour. */
+int toyni_tools_inject(unsigned flags);
+/* NCCL_VERSION_CODE reported by the librccl that dlopen found (0: not loadable / no ncclGetVersion). */
+int toyni_tools_rccl_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,38 @@ def test_integration_sketches_only_use_names_the_rust_module_exports():
     # and INTEGRATION.md says which feature the reference's own call sites need
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "--features cuda" in integ and '`--features hip` alone' in integ
+
+
+def test_hand_declared_rccl_abi_matches_rccl_h():
+    """csrc/multi_gpu.hpp binds librccl with dlopen and declares the five entry points by hand (so that a crate's hip/ directory
+    builds without RCCL's include path).  ADVICE r2: those declarations had never met the real header.  Parse rccl.h and check the
+    enum value of ncclUint32, the parameter lists of the functions used, and that the header's version satisfies the minimum."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    text = open(hdr).read()
+    src = open(os.path.join(ROOT, "toyni_amd", "csrc", "multi_gpu.hpp")).read()
+    assert re.search(r"ncclUint32\s*=\s*3\b", text) and re.search(r"constexpr int RCCL_UINT32 = 3;", src)
+    norm = lambda t: re.sub(r"\s+", " ", t).strip()
+
+    def params(name):
+        m = re.search(r"ncclResult_t\s+%s\s*\(([^)]*)\)\s*;" % name, text)
+        assert m, name
+        out = []
+        for prm in m.group(1).split(","):
+            prm = norm(prm)
+            prm = re.sub(r"\b\w+$", "", prm).strip() if not prm.endswith("*") else prm   # drop the parameter name
+            out.append(prm.replace(" *", "*").replace("* ", "*"))
+        return out
+    assert params("ncclCommInitAll") == ["ncclComm_t*", "int", "const int*"]
+    assert params("ncclSend") == ["const void*", "size_t", "ncclDataType_t", "int", "ncclComm_t", "hipStream_t"]
+    assert params("ncclRecv") == ["void*", "size_t", "ncclDataType_t", "int", "ncclComm_t", "hipStream_t"]
+    assert params("ncclGetVersion") == ["int*"]
+    assert re.search(r"ncclResult_t\s+ncclGroupStart\s*\(\s*(void)?\s*\)", text) and re.search(r"ncclResult_t\s+ncclGroupEnd\s*\(\s*(void)?\s*\)", text)
+    assert re.search(r"typedef struct ncclComm\s*\*\s*ncclComm_t;", text)          # a pointer: `typedef void* rccl_comm_t` has its size
+    # and the hand-written side says the same
+    assert "int (*CommInitAll)(rccl_comm_t*, int, const int*)" in src
+    assert "int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t)" in src
+    assert "int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t)" in src
+    code = int(re.search(r"#define NCCL_VERSION_CODE (\d+)", text).group(1))
+    assert code >= int(re.search(r"RCCL_MIN_VERSION = (\d+);", src).group(1))

@@ -26,6 +26,25 @@ def test_bare_invocation_spawns_ranks(gpus):
     assert out["n_gpus"] == gpus and out["ranks_counted"] == gpus
 
 
+@pytest.mark.parametrize("gpus,batch", [(2, 1024), (4, 1024), (4, 10), (8, 1024)])
+def test_strong_scaling_shards_the_job_total(gpus, batch):
+    """`--scaling strong` = BASELINE configs[3] as written (1024 transforms in the whole job, 1024/G per GPU); the
+    default stays weak (--batch on every GPU), which is what the driver's contract asks for."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for scaling in ("strong", "weak"):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--probe-ranks", "--batch", str(batch)] +
+                             (["--scaling", "strong"] if scaling == "strong" else []),
+                             capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+        out = _last_json(res.stdout)
+        per = [r["transforms_per_step"] // 2 for r in sorted(out["ranks"], key=lambda r: r["rank"])]
+        assert out["scaling"] == scaling and len(per) == gpus
+        if scaling == "strong":
+            assert sum(per) == batch == out["batch_total"] and max(per) - min(per) <= 1 and per == sorted(per, reverse=True)
+        else:
+            assert per == [batch] * gpus and out["batch_total"] == batch * gpus
+
+
 def test_under_a_launcher_no_second_spawn():
     # the contract's other form: the driver starts torch.distributed.run itself; bench.py must then NOT spawn again
     import socket
@@ -52,3 +71,12 @@ def test_two_ranks_on_one_gpu_rehearsal():
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         out = _last_json(res.stdout)
         assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+        if "--batch" in extra:       # the per-rank table: which device every rank used and its own step time
+            assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["ms_per_step"] > 0 and r["transforms_per_step"] == 16 for r in out["ranks"])
+            assert "rank  device  pci" in res.stderr
+    # strong scaling through the real body: 9 transforms over 2 ranks = 5 + 4
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+                          "--no-cpu-baseline", "--batch", "9", "--scaling", "strong"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = _last_json(res.stdout)
+    assert out["scaling"] == "strong" and [r["transforms_per_step"] for r in out["ranks"]] == [10, 8] and out["config"]["batch_total"] == 9

@@ -110,6 +110,89 @@ def test_slab_multi_gpu_rccl_group_of_one(ta):
         ta.ntt_slab_multi_gpu_host(v, [0, 0], exchange=ta.ntt.EXCHANGE_RCCL)
 
 
+def _tools_child(code, extra_env=None):
+    """`code` in a child interpreter bound to libtoyni_hip_tools.so: the fault-injection hook toyni_tools_inject lives there only."""
+    import os
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), TOYNI_LIB_OVERRIDE=entry.build_tools(),
+               **(extra_env or {}))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+
+
+def test_slab_group_refuses_lanes_without_peer_access():
+    """a device pair without direct peer access must surface as TOYNI_E_NO_PEER_ACCESS when the group is built
+    (hipDeviceEnablePeerAccess errors used to be swallowed and hipMemcpyPeerAsync silently staged through the host).  One GPU here,
+    so the denial is injected (bit 0: every pair of different lanes counts as two devices that cannot reach each other)."""
+    code = (
+        "import ctypes, numpy as np, oracle, toyni_amd\n"
+        "lib = toyni_amd._lib.lib\n"
+        "n = 1 << 17\n"
+        "x = oracle.splitmix(n, 9100); v = x.copy()\n"
+        "devs = (ctypes.c_int * 2)(0, 0)\n"
+        "assert lib.toyni_tools_inject(1) == 0\n"
+        "rc = lib.toyni_ntt_slab_multi_gpu_host(devs, 2, n, v.ctypes.data, 0, 0)\n"
+        "assert rc == 10009, rc\n"
+        "assert (v == x).all(), 'a refused call must not touch the data'\n"
+        "assert b'peer access' in lib.toyni_error_string(rc)\n"
+        "one = (ctypes.c_int * 1)(0)\n"
+        "assert lib.toyni_ntt_slab_multi_gpu_host(one, 1, n, v.ctypes.data, 0, 0) == 0   # a single lane has no peers\n"
+        "assert (v == oracle.ntt(x)).all()\n"
+        "assert lib.toyni_tools_inject(0) == 0\n"
+        "v = x.copy()\n"
+        "assert lib.toyni_ntt_slab_multi_gpu_host(devs, 2, n, v.ctypes.data, 0, 0) == 0   # the failed group was not cached\n"
+        "assert (v == oracle.ntt(x)).all()\n"
+        "print('PEER OK')\n")
+    res = _tools_child(code)
+    assert res.returncode == 0 and "PEER OK" in res.stdout, res.stdout[-500:] + res.stderr[-2000:]
+    assert "no peer access" in res.stderr
+
+
+def test_slab_group_first_use_self_check():
+    """on first use a group whose exchange crosses devices runs one n = 2^18 transform through that exchange and compares it
+    with the single-device transform.  Forced here for lanes on one device (bit 1), and with one corrupted word (bit 2) it must fail
+    with TOYNI_E_SELF_CHECK before the caller's data is touched."""
+    code = (
+        "import ctypes, numpy as np, oracle, toyni_amd\n"
+        "lib = toyni_amd._lib.lib\n"
+        "n = 1 << 20\n"
+        "x = oracle.splitmix(n, 9200); v = x.copy()\n"
+        "devs = (ctypes.c_int * 4)(0, 0, 0, 0)\n"
+        "lib.toyni_tools_inject(2)\n"
+        "assert lib.toyni_ntt_slab_multi_gpu_host(devs, 4, n, v.ctypes.data, 0, 0) == 0\n"
+        "assert (v == oracle.ntt(x)).all()\n"
+        "lib.toyni_tools_inject(2 | 4)\n"
+        "v = x.copy()\n"
+        "rc = lib.toyni_ntt_slab_multi_gpu_host(devs, 4, n, v.ctypes.data, 0, 0)\n"
+        "assert rc == 10010, rc\n"
+        "assert (v == x).all()\n"
+        "lib.toyni_tools_inject(0)\n"
+        "print('SELF-CHECK OK')\n")
+    res = _tools_child(code, {"TOYNI_VERBOSE": "1"})
+    assert res.returncode == 0 and "SELF-CHECK OK" in res.stdout, res.stdout[-500:] + res.stderr[-2000:]
+    assert "self-check (4 lanes, peer-copy exchange" in res.stderr and ": ok" in res.stderr and "self-check failed" in res.stderr
+    assert "lane 3/4 -> device 0 (PCI" in res.stderr          # the lane -> device table of TOYNI_VERBOSE
+
+
+def test_multi_device_exchange_on_two_real_devices(ta):
+    """Skipped on the one-GPU boxes of this pool: the first place where hipMemcpyPeerAsync, cross-device event waits and an RCCL
+    group of more than one rank actually run.  Both exchange kinds, host form, against the oracle."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ndev = 2 if torch.cuda.device_count() < 4 else 4
+    for exchange in (ta.ntt.EXCHANGE_PEER_COPY, ta.ntt.EXCHANGE_RCCL):
+        n = 1 << 20
+        x = oracle.splitmix(n, 9300 + exchange)
+        v = x.copy()
+        ta.ntt_slab_multi_gpu_host(v, list(range(ndev)), exchange=exchange)
+        assert (v == oracle.ntt(x)).all()
+        ta.ntt_slab_multi_gpu_host(v, list(range(ndev)), inverse=True, exchange=exchange)
+        assert (v == x).all()
+
+
 def test_slab_multi_gpu_rejects_bad_arguments(ta):
     lib = ta._lib.lib
     v = np.zeros(1 << 16, dtype=np.uint64)

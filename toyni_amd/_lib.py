@@ -83,6 +83,7 @@ SIGNATURES = {
     "toyni_ntt_ext_device": (c_int, [c_void_p, c_void_p, c_u32, c_int, c_void_p]),
     "toyni_fourstep_twiddle_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_ctx_first_pass_points": (c_size, [c_void_p]),
+    "toyni_first_pass_points": (c_size, [c_u32]),
     "toyni_ntt_slab_pass_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_slab_relayout_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_slab_multi_gpu_device": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_void_p, c_int, c_int]),
@@ -126,6 +127,8 @@ TOOLS_SIGNATURES = {
     "toyni_ntt_ctx_timing": (c_int, [c_void_p, c_int]),
     "toyni_ntt_ctx_timing_read": (c_int, [c_void_p, c_void_p, c_void_p]),
     "toyni_ntt_profile_passes": (c_int, [c_void_p, c_void_p, c_size, c_int, c_int, ctypes.POINTER(ctypes.c_float), c_void_p]),
+    "toyni_tools_inject": (c_int, [ctypes.c_uint]),
+    "toyni_tools_rccl_version": (c_int, []),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

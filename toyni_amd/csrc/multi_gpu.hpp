@@ -61,9 +61,15 @@ struct RcclApi {
     int (*Send)(const void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int version = 0;                 // NCCL_VERSION_CODE of the loaded library (major * 10000 + minor * 100 + patch for >= 2.9)
     bool ok = false;
 };
+// tests/test_abi.py parses /opt/rocm/include/rccl/rccl.h and checks this value and the five signatures above against it
 constexpr int RCCL_UINT32 = 3;
+// ncclSend / ncclRecv inside groups exist since NCCL 2.7; the grouped p2p of every RCCL that ships with ROCm >= 5 is newer.  A
+// library that does not report a version at all, or an older one, is treated as absent.
+constexpr int RCCL_MIN_VERSION = 2700;
 
 const RcclApi& rccl() {
     static const RcclApi api = [] {
@@ -77,7 +83,11 @@ const RcclApi& rccl() {
         a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
         a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-        a.ok = a.CommInitAll && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+        a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
+        if (a.GetVersion && a.GetVersion(&a.version) != 0) a.version = 0;
+        a.ok = a.CommInitAll && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.version >= RCCL_MIN_VERSION;
+        if (!a.ok && std::getenv("TOYNI_VERBOSE"))
+            std::fprintf(stderr, "toyni_hip: librccl loaded but unusable (version code %d, need >= %d, or a symbol is missing)\n", a.version, RCCL_MIN_VERSION);
         return a;
     }();
     return api;
@@ -106,6 +116,8 @@ struct SlabGroup {
     uint32_t n = 0;
     size_t m1 = 0, s1 = 0;
     bool rccl_ready = false, host_buffers = false;
+    bool distinct_devices = false;  // at least two lanes on different devices: the exchange crosses a link
+    bool checked[2] = {false, false};  // first-use self-check passed, per exchange kind
     // registered groups live as long as the process; this runs for a group whose construction failed half way
     ~SlabGroup() {
         for (SlabLane& L : lanes) {
@@ -123,6 +135,46 @@ struct SlabGroup {
 };
 
 #define MG_TRY(expr) do { int _rc = (int)(expr); if (_rc) return _rc; } while (0)
+
+// Fault injection for the tests (measurement build only, include/toyni_hip_tools.h: toyni_tools_inject): bit 0 = every pair of
+// different lanes counts as two devices WITHOUT peer access; bit 1 = the first-use self-check also runs for groups whose lanes all
+// sit on one device; bit 2 = the self-check sees one corrupted word (a broken link).  Always 0 in the shipped library.
+#ifdef TOYNI_TOOLS
+std::atomic<unsigned> g_inject{0};
+inline unsigned injected() { return g_inject.load(std::memory_order_relaxed); }
+#else
+constexpr unsigned injected() { return 0u; }
+#endif
+constexpr unsigned INJECT_DENY_PEER = 1u, INJECT_FORCE_SELF_CHECK = 2u, INJECT_CORRUPT = 4u;
+
+// TOYNI_VERBOSE=1: one line per lane (device ordinal, PCI bus id, peer access to the other lanes) when a group is built, so that
+// the first run on a multi-GPU node shows which devices and links it is using.
+bool verbose() {
+    static const bool v = [] { const char* e = std::getenv("TOYNI_VERBOSE"); return e && e[0] && e[0] != '0'; }();
+    return v;
+}
+
+// Direct access from device `self` to device `peer` (xGMI or PCIe P2P).  hipMemcpyPeerAsync also works WITHOUT it -- the runtime
+// then stages every block through host memory, silently, at a fraction of the link rate -- so a group refuses such a pair unless
+// TOYNI_ALLOW_STAGED_PEER=1 says that staged copies are acceptable (the error used to be swallowed).
+int enable_peer(int self, int peer) {
+    if (injected() & INJECT_DENY_PEER) return TOYNI_E_NO_PEER_ACCESS;
+    if (self == peer) return TOYNI_OK;
+    static const bool allow_staged = [] { const char* e = std::getenv("TOYNI_ALLOW_STAGED_PEER"); return e && e[0] == '1'; }();
+    int can = 0;
+    hipError_t e = hipDeviceCanAccessPeer(&can, self, peer);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (!can) {
+        if (verbose() || !allow_staged)
+            std::fprintf(stderr, "toyni_hip: device %d has no peer access to device %d%s\n", self, peer,
+                         allow_staged ? " (TOYNI_ALLOW_STAGED_PEER=1: copies are staged through the host)" : "");
+        return allow_staged ? TOYNI_OK : TOYNI_E_NO_PEER_ACCESS;
+    }
+    e = hipDeviceEnablePeerAccess(peer, 0);   // the current device is `self` (DeviceGuard of the caller)
+    if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return TOYNI_OK; }
+    if (e != hipSuccess) (void)hipGetLastError();
+    return (int)e;
+}
 
 int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
     static std::mutex mu;
@@ -163,10 +215,18 @@ int slab_group(const int* devices, int ndev, uint32_t n, SlabGroup** out) {
             MG_TRY(hipEventCreateWithFlags(&L.got[(size_t)sidx], hipEventDisableTiming));
         }
         MG_TRY(hipMalloc((void**)&L.d_xchg, ((size_t)n / (size_t)ndev) * sizeof(uint32_t)));
-        // direct xGMI access between the lanes' devices (an error here only means "already enabled" or "same device")
+        // direct xGMI access between the lanes' devices: checked, not assumed
         for (int p = 0; p < ndev; ++p)
-            if (devices[p] != L.device && hipDeviceEnablePeerAccess(devices[p], 0) != hipSuccess) (void)hipGetLastError();
+            if (p != d) MG_TRY(enable_peer(L.device, devices[p]));
+        if (verbose()) {
+            char bus[32] = "?";
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, L.device) != hipSuccess) (void)hipGetLastError();
+            std::fprintf(stderr, "toyni_hip: slab group n=2^%d lane %d/%d -> device %d (PCI %s), slab %zu x %zu, row block %zu x %zu\n",
+                         ilog2(n), d, ndev, L.device, bus, m1, s1 / (size_t)ndev, m1 / (size_t)ndev, s1);
+        }
     }
+    for (int a = 0; a < ndev; ++a)
+        for (int b = a + 1; b < ndev; ++b) g->distinct_devices |= devices[a] != devices[b];
     groups.emplace(std::make_pair(key, n), g);
     owner.release();
     *out = g;
@@ -204,12 +264,19 @@ int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPt
             SlabLane& L = g->lanes[a];
             DeviceGuard guard(L.device);      // the communicator's device is current while its calls are queued
             for (size_t b = 0; b < G && queued; ++b) {  // in stream order on the lane's compute stream: no events needed
+                if (b == a && G > 1) continue;          // the lane's own block never enters the communicator (below)
                 queued = api.Send(send(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) == 0 &&
                          api.Recv(recv(a) + b * blk, blk, RCCL_UINT32, (int)b, L.comm, L.stream) == 0;
             }
         }
         const bool closed = api.GroupEnd() == 0;   // the group is closed on the error path too: RCCL's group state is per thread
-        return queued && closed ? TOYNI_OK : TOYNI_E_RCCL;
+        if (!(queued && closed)) return TOYNI_E_RCCL;
+        for (size_t a = 0; a < G && G > 1; ++a) {  // block a of lane a: a device-local copy on the same stream (a group of one keeps
+            SlabLane& L = g->lanes[a];             // the send-to-self form, which is what a one-GPU box can test of the RCCL path)
+            DeviceGuard guard(L.device);
+            MG_TRY(hipMemcpyAsync(recv(a) + a * blk, send(a) + a * blk, blk * sizeof(uint32_t), hipMemcpyDeviceToDevice, L.stream));
+        }
+        return TOYNI_OK;
     }
     for (size_t a = 0; a < G; ++a) {  // every producer marks its outgoing blocks final
         DeviceGuard guard(g->lanes[a].device);
@@ -346,15 +413,34 @@ int slab_run(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bo
     return TOYNI_OK;
 }
 
+// Waits for everything the group has enqueued: the copy streams first (they feed the compute streams), then the compute streams.
 int slab_sync(SlabGroup* g) {
     int rc = TOYNI_OK;
-    for (SlabLane& L : g->lanes) {
-        DeviceGuard guard(L.device);
-        hipError_t e = hipStreamSynchronize(L.stream);
-        if (e != hipSuccess && rc == TOYNI_OK) rc = (int)e;
-    }
+    for (int phase = 0; phase < 2; ++phase)
+        for (SlabLane& L : g->lanes) {
+            DeviceGuard guard(L.device);
+            if (phase == 0) {
+                for (hipStream_t cs : L.pull) {
+                    hipError_t e = cs ? hipStreamSynchronize(cs) : hipSuccess;
+                    if (e != hipSuccess && rc == TOYNI_OK) rc = (int)e;
+                }
+            } else {
+                hipError_t e = L.stream ? hipStreamSynchronize(L.stream) : hipSuccess;
+                if (e != hipSuccess && rc == TOYNI_OK) rc = (int)e;
+            }
+        }
     return rc;
 }
+
+// Drain on EVERY exit path of a blocking entry point: an early return between enqueued uploads, peer copies, kernels and
+// downloads must not hand the caller's host slice or device buffers back while a stream still reads or writes them.
+struct SlabDrain {
+    SlabGroup* g;
+    bool armed = true;
+    explicit SlabDrain(SlabGroup* g_) : g(g_) {}
+    int finish() { armed = false; return slab_sync(g); }
+    ~SlabDrain() { if (armed) (void)slab_sync(g); }
+};
 
 // [R][C] -> [C][R] through a 32 x 33 LDS tile, converting the element type (u32 -> u64 widens, u64 -> u32 reduces like
 // BabyBear::new): the natural-order <-> row-block re-layout of the host form, on the device (PCIe then moves whole runs)
@@ -384,14 +470,106 @@ __global__ void __launch_bounds__(256) transpose_convert_kernel(const IN* __rest
 int slab_host_buffers(SlabGroup* g) {
     if (g->host_buffers) return TOYNI_OK;
     const size_t per = (size_t)g->n / g->lanes.size();
-    for (SlabLane& L : g->lanes) {
+    for (SlabLane& L : g->lanes) {  // a call that failed half way left some of these allocated: only the missing ones are made
         DeviceGuard guard(L.device);
-        MG_TRY(hipMalloc((void**)&L.d_slab, per * sizeof(uint32_t)));
-        MG_TRY(hipMalloc((void**)&L.d_rows, per * sizeof(uint32_t)));
-        MG_TRY(hipMalloc((void**)&L.d_stage, per * sizeof(uint64_t)));
+        if (!L.d_slab) MG_TRY(hipMalloc((void**)&L.d_slab, per * sizeof(uint32_t)));
+        if (!L.d_rows) MG_TRY(hipMalloc((void**)&L.d_rows, per * sizeof(uint32_t)));
+        if (!L.d_stage) MG_TRY(hipMalloc((void**)&L.d_stage, per * sizeof(uint64_t)));
     }
     g->host_buffers = true;
     return TOYNI_OK;
+}
+
+// Host slice in natural order, in place: n u64 elements.  Per lane: strided upload of its column slab (forward) or its
+// row block (inverse), the device form, and the mirror-image download; the natural-order <-> row-block transposition
+// runs on the device, so PCIe moves runs of S1 / G (slab) or M1 / G (rows) elements.
+int slab_host_transform(const int* devices, int ndev, uint32_t n, uint64_t* h_data, bool inverse, int exchange) {
+    SlabGroup* g = nullptr;
+    MG_TRY(slab_group(devices, ndev, n, &g));
+    std::lock_guard<std::mutex> lk(g->mu);
+    SlabDrain drain(g);   // every return below waits for the lanes' streams first: h_data is the caller's memory
+    MG_TRY(slab_host_buffers(g));
+    const size_t G = g->lanes.size(), m1 = g->m1, s1 = g->s1, w = s1 / G, r = m1 / G, per = (size_t)n / G;
+    std::vector<uint32_t*> slabs(G), rows(G);
+    for (size_t a = 0; a < G; ++a) { slabs[a] = g->lanes[a].d_slab; rows[a] = g->lanes[a].d_rows; }
+    for (size_t a = 0; a < G; ++a) {
+        SlabLane& L = g->lanes[a];
+        DeviceGuard guard(L.device);
+        if (!inverse) {
+            // slab [M1][w]: element (j1, c) = x[j1 S1 + a w + c]
+            MG_TRY(hipMemcpy2DAsync(L.d_stage, w * sizeof(uint64_t), h_data + a * w, s1 * sizeof(uint64_t), w * sizeof(uint64_t), m1,
+                                    hipMemcpyHostToDevice, L.stream));
+            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint64_t*)L.d_stage, L.d_slab, per);
+        } else {
+            // rows [r][S1]: element (rr, k') = X[(a r + rr) + M1 k'] -> upload [S1][r] runs, transpose on the device
+            MG_TRY(hipMemcpy2DAsync(L.d_stage, r * sizeof(uint64_t), h_data + a * r, m1 * sizeof(uint64_t), r * sizeof(uint64_t), s1,
+                                    hipMemcpyHostToDevice, L.stream));
+            hipLaunchKernelGGL((transpose_convert_kernel<uint64_t, uint32_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
+                               (const uint64_t*)L.d_stage, L.d_rows, (uint32_t)s1, (uint32_t)r);
+        }
+        MG_TRY(hipGetLastError());
+    }
+    MG_TRY(slab_run(g, slabs.data(), rows.data(), inverse, exchange));
+    for (size_t a = 0; a < G; ++a) {
+        SlabLane& L = g->lanes[a];
+        DeviceGuard guard(L.device);
+        if (!inverse) {
+            hipLaunchKernelGGL((transpose_convert_kernel<uint32_t, uint64_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
+                               (const uint32_t*)L.d_rows, L.d_stage, (uint32_t)r, (uint32_t)s1);
+            MG_TRY(hipGetLastError());
+            MG_TRY(hipMemcpy2DAsync(h_data + a * r, m1 * sizeof(uint64_t), L.d_stage, r * sizeof(uint64_t), r * sizeof(uint64_t), s1,
+                                    hipMemcpyDeviceToHost, L.stream));
+        } else {
+            hipLaunchKernelGGL(widen_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint32_t*)L.d_slab, L.d_stage, per);
+            MG_TRY(hipGetLastError());
+            MG_TRY(hipMemcpy2DAsync(h_data + a * w, s1 * sizeof(uint64_t), L.d_stage, w * sizeof(uint64_t), w * sizeof(uint64_t), m1,
+                                    hipMemcpyDeviceToHost, L.stream));
+        }
+    }
+    return drain.finish();
+}
+
+// First use of a device list whose exchange crosses a link (no cross-device copy, event wait or RCCL group of more than
+// one rank had ever run when this was written): one small transform (n = 2^18, 1 MiB) goes through exactly the code path of the
+// real call -- same devices, same exchange kind -- and is compared with the SINGLE-device transform of the same input, forward and
+// back.  A wrong block order, a copy that raced its producer or a mis-declared RCCL signature shows up here as TOYNI_E_SELF_CHECK
+// instead of as a silently wrong proof.  Costs a few milliseconds once per (device list, exchange) and process.
+constexpr uint32_t SELF_CHECK_N = 1u << 18;
+int slab_self_check(const int* devices, int ndev, int exchange) {
+    if (ndev < 2) return TOYNI_OK;
+    bool distinct = false;
+    for (int a = 0; a < ndev; ++a) for (int b = a + 1; b < ndev; ++b) distinct |= devices[a] != devices[b];
+    if (!distinct && !(injected() & INJECT_FORCE_SELF_CHECK)) return TOYNI_OK;
+    static std::mutex mu;
+    static std::map<std::pair<std::vector<int>, int>, int> verdicts;  // process lifetime
+    std::lock_guard<std::mutex> lk(mu);
+    const std::pair<std::vector<int>, int> key(std::vector<int>(devices, devices + ndev), exchange);
+    const auto it = verdicts.find(key);
+    if (it != verdicts.end() && !(injected() & INJECT_FORCE_SELF_CHECK)) return it->second;
+    const size_t n = SELF_CHECK_N;
+    std::vector<uint64_t> x(n), ref(n), got(n);
+    uint64_t state = 0x70796E69u;
+    for (size_t i = 0; i < n; ++i) {  // splitmix64 residues: every block of the exchange carries different words
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        x[i] = (z ^ (z >> 31)) % BB_P;
+    }
+    ref = x;
+    got = x;
+    int rc = TOYNI_OK;
+    toyni_ntt_ctx* single = nullptr;
+    if ((rc = cached_ctx(devices[0], 0, SELF_CHECK_N, &single)) == TOYNI_OK) rc = toyni_ntt_host(single, ref.data(), 1, 0);
+    if (rc == TOYNI_OK) rc = slab_host_transform(devices, ndev, SELF_CHECK_N, got.data(), false, exchange);
+    if (rc == TOYNI_OK && (injected() & INJECT_CORRUPT)) got[n / 2 + 5] ^= 1u;
+    if (rc == TOYNI_OK && std::memcmp(ref.data(), got.data(), n * sizeof(uint64_t)) != 0) rc = TOYNI_E_SELF_CHECK;
+    if (rc == TOYNI_OK) rc = slab_host_transform(devices, ndev, SELF_CHECK_N, got.data(), true, exchange);
+    if (rc == TOYNI_OK && std::memcmp(x.data(), got.data(), n * sizeof(uint64_t)) != 0) rc = TOYNI_E_SELF_CHECK;
+    if (verbose() || rc != TOYNI_OK)
+        std::fprintf(stderr, "toyni_hip: multi-device self-check (%d lanes, %s exchange, n = 2^18 against device %d alone): %s\n", ndev,
+                     exchange == TOYNI_EXCHANGE_RCCL ? "RCCL" : "peer-copy", devices[0], rc == TOYNI_OK ? "ok" : toyni_error_string(rc));
+    verdicts[key] = rc;
+    return rc;
 }
 
 }  // namespace
@@ -430,66 +608,32 @@ int toyni_ntt_slab_multi_gpu_device(const int* devices, int ndev, uint32_t n, ui
     if (!devices || !d_slabs || !d_rows) return TOYNI_E_NULL;
     if (ndev < 1 || (ndev & (ndev - 1))) return TOYNI_E_RANGE;
     if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
+    if (exchange != TOYNI_EXCHANGE_PEER_COPY && exchange != TOYNI_EXCHANGE_RCCL) return TOYNI_E_RANGE;
     for (int d = 0; d < ndev; ++d) if (!d_slabs[d] || !d_rows[d]) return TOYNI_E_NULL;
+    MG_TRY(slab_self_check(devices, ndev, exchange));
     SlabGroup* g = nullptr;
     MG_TRY(slab_group(devices, ndev, n, &g));
     std::lock_guard<std::mutex> lk(g->mu);
-    int rc = slab_run(g, d_slabs, d_rows, inverse != 0, exchange);
-    const int rs = slab_sync(g);
+    SlabDrain drain(g);
+    const int rc = slab_run(g, d_slabs, d_rows, inverse != 0, exchange);
+    const int rs = drain.finish();
     return rc ? rc : rs;
 }
 
-// Host slice in natural order, in place: n u64 elements.  Per lane: strided upload of its column slab (forward) or its
-// row block (inverse), the device form above, and the mirror-image download; the natural-order <-> row-block transposition
-// runs on the device, so PCIe moves runs of S1 / G (slab) or M1 / G (rows) elements.
+// Host slice in natural order, in place (slab_host_transform above), after the group's first-use self-check.
 int toyni_ntt_slab_multi_gpu_host(const int* devices, int ndev, uint32_t n, uint64_t* h_data, int inverse, int exchange) {
     if (!devices || !h_data) return TOYNI_E_NULL;
     if (ndev < 1 || (ndev & (ndev - 1))) return TOYNI_E_RANGE;
     if (!is_pow2(n) || ilog2(n) > MAX_LOG_N) return TOYNI_E_INVALID_SIZE;
-    SlabGroup* g = nullptr;
-    MG_TRY(slab_group(devices, ndev, n, &g));
-    std::lock_guard<std::mutex> lk(g->mu);
-    MG_TRY(slab_host_buffers(g));
-    const size_t G = g->lanes.size(), m1 = g->m1, s1 = g->s1, w = s1 / G, r = m1 / G, per = (size_t)n / G;
-    std::vector<uint32_t*> slabs(G), rows(G);
-    for (size_t a = 0; a < G; ++a) { slabs[a] = g->lanes[a].d_slab; rows[a] = g->lanes[a].d_rows; }
-    for (size_t a = 0; a < G; ++a) {
-        SlabLane& L = g->lanes[a];
-        DeviceGuard guard(L.device);
-        if (!inverse) {
-            // slab [M1][w]: element (j1, c) = x[j1 S1 + a w + c]
-            MG_TRY(hipMemcpy2DAsync(L.d_stage, w * sizeof(uint64_t), h_data + a * w, s1 * sizeof(uint64_t), w * sizeof(uint64_t), m1,
-                                    hipMemcpyHostToDevice, L.stream));
-            hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint64_t*)L.d_stage, L.d_slab, per);
-        } else {
-            // rows [r][S1]: element (rr, k') = X[(a r + rr) + M1 k'] -> upload [S1][r] runs, transpose on the device
-            MG_TRY(hipMemcpy2DAsync(L.d_stage, r * sizeof(uint64_t), h_data + a * r, m1 * sizeof(uint64_t), r * sizeof(uint64_t), s1,
-                                    hipMemcpyHostToDevice, L.stream));
-            hipLaunchKernelGGL((transpose_convert_kernel<uint64_t, uint32_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
-                               (const uint64_t*)L.d_stage, L.d_rows, (uint32_t)s1, (uint32_t)r);
-        }
-        MG_TRY(hipGetLastError());
-    }
-    int rc = slab_run(g, slabs.data(), rows.data(), inverse != 0, exchange);
-    if (rc) { (void)slab_sync(g); return rc; }
-    for (size_t a = 0; a < G; ++a) {
-        SlabLane& L = g->lanes[a];
-        DeviceGuard guard(L.device);
-        if (!inverse) {
-            hipLaunchKernelGGL((transpose_convert_kernel<uint32_t, uint64_t>), dim3(grid_for(per, 1024)), dim3(256), 0, L.stream,
-                               (const uint32_t*)L.d_rows, L.d_stage, (uint32_t)r, (uint32_t)s1);
-            MG_TRY(hipGetLastError());
-            MG_TRY(hipMemcpy2DAsync(h_data + a * r, m1 * sizeof(uint64_t), L.d_stage, r * sizeof(uint64_t), r * sizeof(uint64_t), s1,
-                                    hipMemcpyDeviceToHost, L.stream));
-        } else {
-            hipLaunchKernelGGL(widen_kernel, dim3(grid_for(per)), dim3(256), 0, L.stream, (const uint32_t*)L.d_slab, L.d_stage, per);
-            MG_TRY(hipGetLastError());
-            MG_TRY(hipMemcpy2DAsync(h_data + a * w, s1 * sizeof(uint64_t), L.d_stage, w * sizeof(uint64_t), w * sizeof(uint64_t), m1,
-                                    hipMemcpyDeviceToHost, L.stream));
-        }
-    }
-    return slab_sync(g);
+    if (exchange != TOYNI_EXCHANGE_PEER_COPY && exchange != TOYNI_EXCHANGE_RCCL) return TOYNI_E_RANGE;
+    MG_TRY(slab_self_check(devices, ndev, exchange));
+    return slab_host_transform(devices, ndev, n, h_data, inverse != 0, exchange);
 }
+
+#ifdef TOYNI_TOOLS  // include/toyni_hip_tools.h
+int toyni_tools_inject(unsigned flags) { g_inject.store(flags, std::memory_order_relaxed); return TOYNI_OK; }
+int toyni_tools_rccl_version(void) { return rccl().version; }
+#endif
 
 }  // extern "C"
 #undef MG_TRY

@@ -123,10 +123,17 @@ using BufRsrc = __amdgpu_buffer_rsrc_t;
 TOYNI_HD BufRsrc buf_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000); }
 template <bool NT = false>
 TOYNI_HD uint32_t ldb32(BufRsrc r, uint32_t voff, uint32_t soff) {
+#if TOYNI_ABLATE & 1
+    return voff + soff;
+#else
     return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, NT ? 2 : 0);
+#endif
 }
 template <bool NT = false>
 TOYNI_HD void stb32(BufRsrc r, uint32_t voff, uint32_t soff, uint32_t v) {
+#if TOYNI_ABLATE & 2
+    if (v == 0xFFFFFFFFu)
+#endif
     __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, NT ? 2 : 0);
 }
 #else

@@ -188,15 +188,21 @@ inline bool build_plan(int log_n, NttPlan& plan, bool latency = false) {
 // and the chip is far from full) run the three-step shapes `Pass3` with 4-wide tiles instead: 8x the workgroups of the 32-wide
 // shape and half the serial work per wave.  -1 = never.  (A variable so that tests/emu can step both executors and the library
 // can take TOYNI_P3_TILES from the environment.)
+// The three dispatch knobs below take their value from the environment ONCE, in their thread-safe static initialiser; the library
+// never writes them afterwards (tests/emu does, to step both executors).
+inline int plan_env_int(const char* name, int dflt) {
+    const char* env = std::getenv(name);
+    return env ? std::atoi(env) : dflt;
+}
 inline int& pass3_max_log_tiles32() {
-    static int v = 6;
+    static int v = plan_env_int("TOYNI_P3_TILES", 6);   // -1: never the three-step shapes
     return v;
 }
 
 // launches that take the two-pass latency plan of n = 2^21 / 2^22 (has_latency_plan): those whose first pass has at most this
 // many (log2) 32-wide tiles' worth of columns
 inline int& lat_max_log_tiles32() {
-    static int v = 7;
+    static int v = plan_env_int("TOYNI_LAT_TILES", 7);  // -1: never the two-pass latency plans
     return v;
 }
 
@@ -208,7 +214,7 @@ inline int& lat_max_log_tiles32() {
 #define TOYNI_WIDE_54 6
 #endif
 inline int& wide_min_log_tiles32() {
-    static int v = 12;
+    static int v = plan_env_int("TOYNI_WIDE_TILES", 12);  // 99: never the 64-wide shapes
     return v;
 }
 

@@ -80,14 +80,12 @@ def fourstep_input_index(log_n: int, world: int, rank: int) -> torch.Tensor:
 
 
 def first_pass_log(log_n: int) -> int:
-    """log2 M1 of the single-device plan (toyni_amd/csrc/ntt_plan.hpp split_passes); 0 when the transform is single-pass."""
-    if log_n <= 10:
-        return 0
-    small_first = os.environ.get("TOYNI_SPLIT_SMALL_FIRST", "1")[:1] != "0"   # the larger factor goes to the LAST pass (ntt_plan.hpp)
-    if log_n <= 20:
-        hi, lo = (log_n + 1) // 2, log_n // 2
-        return lo if small_first and lo >= 6 else hi
-    return log_n // 3 if small_first else (log_n + 2) // 3
+    """log2 M1 of the single-device plan; 0 when the transform is single-pass.  Asked of the LIBRARY (toyni_first_pass_points:
+    split_passes of toyni_amd/csrc/ntt_plan.hpp, no device needed), not re-derived here: the split is the slab layout contract, and
+    a second copy of the rule could drift from the one the kernels follow."""
+    from ._lib import lib
+    m1 = int(lib.toyni_first_pass_points(1 << log_n)) if 0 <= log_n <= 27 else 0
+    return m1.bit_length() - 1 if m1 else 0
 
 
 def slab_split(log_n: int, world: int) -> Tuple[int, int]:

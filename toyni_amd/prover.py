@@ -30,8 +30,8 @@ def fri_commit_phase_device(ctx, d_layer0: int, m0: int, x0: int, final_size: in
             if beta_ptr:
                 beta_ptr[0] = int(beta)
             return 0
-        except Exception as e:  # noqa: BLE001  (an exception must not unwind through the C frames)
-            failure.append(e)
+        except BaseException as e:  # noqa: BLE001  (nothing may unwind through the C frames -- KeyboardInterrupt included: ctypes
+            failure.append(e)       # would print and swallow it, return 0, and the C loop would go on with beta = 0; re-raised below)
             return 1
 
     cb = FRI_CHALLENGE_FN(_cb)
