@@ -14,10 +14,15 @@
  * Threading and streams: a context serialises the ENQUEUEING of its calls with an internal mutex, and keeps its
  * intermediate buffers per stream: calls enqueued on one stream are ordered by that stream, calls enqueued on different
  * streams use different buffers.  So one context may be driven from several host threads and several streams at once
- * (the reference's single shared d_data -- SURVEY.md F8, cuda/ntt_kernel.cu:205 -- has no counterpart).  Nothing is freed
- * on an enqueue path: an outgrown buffer is released after the next synchronisation of its stream through this API
- * (blocking entry points, toyni_stream_synchronize) or by toyni_ntt_ctx_trim / toyni_ntt_ctx_destroy.  At most 8 streams'
- * buffer sets are kept per context (least recently used first out).
+ * (the reference's single shared d_data -- SURVEY.md F8, cuda/ntt_kernel.cu:205 -- has no counterpart).  At most 8 streams'
+ * buffer sets are kept per context (least recently used first out).  Memory stays bounded without any call from the user
+ * (round 3): a buffer that was outgrown, or that belonged to an evicted set, carries a HIP event recorded on its stream after its
+ * last use, and the next call on the context that finds the event complete frees it (hipFree synchronises the device, so this
+ * never happens on the enqueue path of a steady-state caller -- there is nothing to free there).  A context that serves ONE stream
+ * with small calls (intermediates under 64 MiB: the latency path) records no events at all; with several streams, or large
+ * intermediates, every call ends with one hipEventRecord (TOYNI_FENCE=always|never overrides).
+ * Synchronising a stream through this API (blocking entry points, toyni_stream_synchronize), toyni_ntt_ctx_trim and
+ * toyni_ntt_ctx_destroy release retired buffers as before.  Calls captured into a HIP graph leave no fence.
  */
 #ifndef TOYNI_HIP_H
 #define TOYNI_HIP_H
@@ -294,6 +299,10 @@ int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream);
 int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream);
+/* Streams for host languages that bind only this library: device -1 = the current device; the stream is non-blocking with respect
+ * to HIP's legacy default stream.  toyni_stream_destroy waits for the stream's work first. */
+int toyni_stream_create(void** stream, int device);
+int toyni_stream_destroy(void* stream);
 int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); with a context: also releases what that stream outgrew */
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);

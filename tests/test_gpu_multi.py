@@ -262,6 +262,61 @@ def test_many_streams_evict_scratch_sets(ta):
     ctx.destroy()
 
 
+def test_short_lived_streams_do_not_accumulate_scratch(ta):
+    """a caller that cycles through short-lived streams used to grow device memory without bound (an evicted
+    scratch set waited for toyni_ntt_ctx_trim: its stream might be gone, so nothing could be recorded on it at eviction time).  Now
+    every call of a multi-stream context leaves a fence on its stream and evicted sets are freed by a later call once their fence has
+    completed.  64 streams x (256 x 2^20): each set holds a 1 GiB intermediate; without the fix this would pin ~56 GiB."""
+    import torch
+    lib = ta._lib.lib
+    n, batch = 1 << 20, 256
+    set_bytes = batch * n * 4
+    ctx = ta.NttContext(n)
+    data = torch.randint(0, P, (batch * n,), dtype=torch.int32, device="cuda")
+    keep = data.clone()
+
+    def one_stream():
+        st = ctypes.c_void_p()
+        assert lib.toyni_stream_create(ctypes.byref(st), -1) == 0
+        ctx.run_device(data.data_ptr(), data.data_ptr(), batch, False, stream=st.value)
+        ctx.run_device(data.data_ptr(), data.data_ptr(), batch, True, stream=st.value)
+        assert lib.toyni_stream_destroy(st) == 0          # waits, then destroys: the next stream starts on settled data
+
+    torch.cuda.synchronize()
+    for _ in range(8):                                     # fill the context's 8 cached sets
+        one_stream()
+    torch.cuda.synchronize()
+    free_start = torch.cuda.mem_get_info()[0]
+    low = free_start
+    for _ in range(56):
+        one_stream()
+        low = min(low, torch.cuda.mem_get_info()[0])
+    torch.cuda.synchronize()
+    one_stream()                                           # any later call frees what has drained (no trim, no API-level sync)
+    free_end = torch.cuda.mem_get_info()[0]
+    assert torch.equal(data, keep)
+    assert free_start - free_end <= set_bytes + (64 << 20), f"{(free_start - free_end) / 2**30:.2f} GiB still held after 64 streams"
+    assert free_start - low <= 3 * set_bytes, f"peak growth {(free_start - low) / 2**30:.2f} GiB: evicted sets are not being freed as the streams come and go"
+    # growing the batch on ONE stream that is never synchronised through the API: every outgrown buffer is fenced and freed too
+    st = ctypes.c_void_p()
+    assert lib.toyni_stream_create(ctypes.byref(st), -1) == 0
+    ctx2 = ta.NttContext(n)
+    free0 = torch.cuda.mem_get_info()[0]
+    for b in range(8, 264, 8):
+        ctx2.run_device(data.data_ptr(), data.data_ptr(), b, False, stream=st.value)
+        ctx2.run_device(data.data_ptr(), data.data_ptr(), b, True, stream=st.value)
+    torch.cuda.synchronize()
+    ctx2.run_device(data.data_ptr(), data.data_ptr(), 1, False, stream=st.value)
+    ctx2.run_device(data.data_ptr(), data.data_ptr(), 1, True, stream=st.value)
+    torch.cuda.synchronize()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held <= (256 + 16) * n * 4, f"{held / 2**30:.2f} GiB held after growing to 256 transforms (sum of all sizes would be 16.5 GiB)"
+    assert torch.equal(data, keep)
+    assert lib.toyni_stream_destroy(st) == 0
+    ctx.destroy()
+    ctx2.destroy()
+
+
 def test_host_fold_staging_repeated_calls_and_zero_points(ta):
     rng = np.random.default_rng(9)
     for m in (2, 6, 64, 1 << 12, 1 << 16, 10, 1 << 12):       # growing and shrinking: the staging set is reused

@@ -158,7 +158,10 @@ bool verbose() {
 // then stages every block through host memory, silently, at a fraction of the link rate -- so a group refuses such a pair unless
 // TOYNI_ALLOW_STAGED_PEER=1 says that staged copies are acceptable (the error used to be swallowed).
 int enable_peer(int self, int peer) {
-    if (injected() & INJECT_DENY_PEER) return TOYNI_E_NO_PEER_ACCESS;
+    if (injected() & INJECT_DENY_PEER) {
+        std::fprintf(stderr, "toyni_hip: device %d has no peer access to device %d (injected by the test hook)\n", self, peer);
+        return TOYNI_E_NO_PEER_ACCESS;
+    }
     if (self == peer) return TOYNI_OK;
     static const bool allow_staged = [] { const char* e = std::getenv("TOYNI_ALLOW_STAGED_PEER"); return e && e[0] == '1'; }();
     int can = 0;

@@ -667,13 +667,19 @@ struct toyni_ntt_ctx {
         uint32_t* d_lde32 = nullptr;     // compact coefficient vectors of the LDE entry points
         size_t lde32_words = 0;
         uint64_t tick = 0;               // last use (eviction order)
+        hipEvent_t fence = nullptr;      // recorded on the set's stream at the end of the last call that used it (when `fenced`)
+        bool fenced = false;             // `fence` covers every use of the set so far
+        bool dirty = false;              // used by the call in progress (finish_call records the fence)
     };
     std::map<hipStream_t, Scratch> scratch;
     uint64_t tick = 0;
     // Buffers that were outgrown or evicted.  They may still be read by kernels in flight, and hipFree is a device-wide
     // synchronisation, so nothing is freed on an enqueue path: a retired buffer is freed after a synchronisation of the
     // stream it belonged to (blocking host entry points, toyni_stream_synchronize), by toyni_ntt_ctx_trim, or at destroy.
-    struct Retired { void* ptr; hipStream_t stream; bool stream_known; };
+    // Round 3: a retired buffer that has an EVENT (recorded on its stream after its last possible use) is freed by the next
+    // call on this context that finds the event complete -- so a caller that cycles through short-lived streams, or grows its
+    // batch on a stream it never synchronises through this API, no longer accumulates buffers until trim.
+    struct Retired { void* ptr; hipStream_t stream; bool stream_known; hipEvent_t ev; bool fresh; };
     std::vector<Retired> retired;
     size_t chunk_elems = 0;          // 0 = whole batch in one launch sequence
     int num_cus = 256;
@@ -707,9 +713,15 @@ namespace {
 // the context locked, so an entry point on the same context from inside it would deadlock on c->mu; it returns
 // TOYNI_E_REENTRANT instead (the rule was documented but not enforced).
 thread_local const toyni_ntt_ctx* t_callback_ctx = nullptr;
+void finish_call(toyni_ntt_ctx* c);
+struct CtxCall {   // declared right after the lock: destroyed before it is released
+    toyni_ntt_ctx* c;
+    ~CtxCall() { finish_call(c); }
+};
 #define TOYNI_CTX_LOCK(c)                                   \
     if (t_callback_ctx == (c)) return TOYNI_E_REENTRANT;   \
-    std::lock_guard<std::mutex> lk((c)->mu)
+    std::lock_guard<std::mutex> lk((c)->mu);               \
+    CtxCall _ctx_call{(c)}
 
 struct DeviceGuard {
     int prev = -1;
@@ -722,9 +734,29 @@ struct DeviceGuard {
 
 constexpr size_t MAX_SCRATCH_STREAMS = 8;
 
+// Fencing policy (TOYNI_FENCE = auto | always | never; read once).  A fence is one hipEventRecord at the end of a call, on every
+// stream whose scratch set the call used.  auto (default): while the context serves more than one stream, and for any set that
+// holds >= 64 MiB -- so a lone small transform on a single stream (the latency path) records nothing.  The one hole of `auto`: a
+// SMALL set of the first stream, last used before a second stream appeared, is unfenced; evicted, it waits for trim like in
+// round 2 (at most one set of < 64 MiB per context).
+int fence_mode() {
+    static const int v = [] {
+        const char* e = std::getenv("TOYNI_FENCE");
+        if (e && !std::strcmp(e, "always")) return 2;
+        if (e && !std::strcmp(e, "never")) return 0;
+        return 1;
+    }();
+    return v;
+}
+
 void retire_scratch(toyni_ntt_ctx* c, toyni_ntt_ctx::Scratch& sc, hipStream_t s, bool stream_known) {
+    // an evicted set's stream may no longer exist, so nothing can be recorded on it now: the set's own fence, recorded when the
+    // stream was last used, is what lets its buffers go (one event shared by the set's buffers: the last one to go destroys it)
+    hipEvent_t ev = (sc.fenced && !sc.dirty) ? sc.fence : nullptr;
+    bool handed = false;
     for (void* p : {(void*)sc.d_work, (void*)sc.d_data32, (void*)sc.d_stage64, (void*)sc.d_lde32})
-        if (p) c->retired.push_back({p, s, stream_known});
+        if (p) { c->retired.push_back({p, s, stream_known, ev, false}); handed = true; }
+    if (sc.fence && !(ev && handed)) (void)hipEventDestroy(sc.fence);
     sc = toyni_ntt_ctx::Scratch();
 }
 
@@ -743,25 +775,101 @@ toyni_ntt_ctx::Scratch& scratch_for(toyni_ntt_ctx* c, hipStream_t s) {
         it = c->scratch.emplace(s, toyni_ntt_ctx::Scratch()).first;
     }
     it->second.tick = ++c->tick;
+    it->second.dirty = true;
     return it->second;
 }
 
 // grow-only; the outgrown buffer is retired, not freed (no hipFree -- a device-wide sync -- on an enqueue path)
 int grow(toyni_ntt_ctx* c, hipStream_t s, void** buf, size_t* have, size_t need, size_t elem_bytes) {
     if (*have >= need) return 0;
-    if (*buf) { c->retired.push_back({*buf, s, true}); *buf = nullptr; *have = 0; }
+    if (*buf) { c->retired.push_back({*buf, s, true, nullptr, true}); *buf = nullptr; *have = 0; }   // fresh: finish_call fences it on s
     HIPCHK(hipMalloc(buf, need * elem_bytes));
     *have = need;
     return 0;
 }
 
 // after stream s has been synchronised by the caller: nothing enqueued on it can still touch what it retired
+// several retired buffers may share one event (an evicted set): it is destroyed with the last of them
+void drop_retired_event(toyni_ntt_ctx* c, size_t index) {
+    hipEvent_t ev = c->retired[index].ev;
+    if (!ev) return;
+    for (size_t j = 0; j < c->retired.size(); ++j)
+        if (j != index && c->retired[j].ev == ev) return;
+    (void)hipEventDestroy(ev);
+}
+
 void reclaim_after_sync(toyni_ntt_ctx* c, hipStream_t s) {
     size_t keep = 0;
-    for (auto& r : c->retired) {
-        if (r.stream_known && r.stream == s) (void)hipFree(r.ptr);
-        else c->retired[keep++] = r;
+    for (size_t i = 0; i < c->retired.size(); ++i) {
+        auto& r = c->retired[i];
+        if (r.stream_known && r.stream == s) { (void)hipFree(r.ptr); r.ptr = nullptr; }
     }
+    for (size_t i = 0; i < c->retired.size(); ++i)
+        if (!c->retired[i].ptr) drop_retired_event(c, i);
+    for (auto& r : c->retired)
+        if (r.ptr) c->retired[keep++] = r;
+    c->retired.resize(keep);
+}
+
+// End of every call on a context (TOYNI_CTX_LOCK's guard; the context is still locked): fence what the call used, then free the
+// retired buffers whose fence has completed.  Steady state (one stream, nothing retired): two empty loops.
+void finish_call(toyni_ntt_ctx* c) {
+    bool fresh = false;
+    for (auto& r : c->retired) fresh |= r.fresh;
+    const int mode = fence_mode();
+    const bool fence_sets = mode == 2 || (mode == 1 && c->scratch.size() > 1);
+    bool any_dirty = false;
+    for (auto& kv : c->scratch) any_dirty |= kv.second.dirty;
+    if (!any_dirty && !fresh && c->retired.empty()) return;
+    DeviceGuard guard(c->device);
+    for (auto& kv : c->scratch) {
+        toyni_ntt_ctx::Scratch& sc = kv.second;
+        if (!sc.dirty) continue;
+        sc.dirty = false;
+        sc.fenced = false;
+        // a set that holds real memory is fenced in single-stream use too: its calls are long (the event is noise next to them) and
+        // an unfenced eviction would pin that memory until trim; small sets (lone transforms: the latency path) stay event-free
+        const size_t set_bytes = sc.work_words * 4 + sc.data32_words * 4 + sc.stage64_elems * 8 + sc.lde32_words * 4;
+        bool need = fence_sets || set_bytes >= ((size_t)64 << 20);
+        for (auto& r : c->retired) need |= r.fresh && r.stream == kv.first;
+        if (!need || mode == 0) continue;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(kv.first, &cap) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (cap != hipStreamCaptureStatusNone) continue;        // a captured call leaves no fence: replays are not this call
+        if (!sc.fence && hipEventCreateWithFlags(&sc.fence, hipEventDisableTiming) != hipSuccess) { sc.fence = nullptr; (void)hipGetLastError(); continue; }
+        if (hipEventRecord(sc.fence, kv.first) != hipSuccess) { (void)hipGetLastError(); continue; }
+        sc.fenced = true;
+        // what this call outgrew on this stream: everything enqueued before the fence is the last that can touch it.  The buffer
+        // gets an event of its own (the set's fence moves on with the next call).
+        for (auto& r : c->retired) {
+            if (!(r.fresh && r.stream == kv.first)) continue;
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, kv.first) == hipSuccess) r.ev = ev;
+            else { if (ev) (void)hipEventDestroy(ev); (void)hipGetLastError(); }
+        }
+    }
+    for (auto& r : c->retired) r.fresh = false;
+    // free what has drained.  hipFree synchronises the device, which is why nothing is freed on the enqueue path of a steady-state
+    // caller -- but there IS nothing to free there; this runs only after an eviction or an outgrown buffer.  Relaxed capture mode:
+    // a hipFree must not invalidate a capture this thread has open on some stream.
+    bool any_ready = false;
+    for (auto& r : c->retired)
+        if (r.ev && hipEventQuery(r.ev) == hipSuccess) { any_ready = true; break; }
+    (void)hipGetLastError();   // hipErrorNotReady from the queries is not an error
+    if (!any_ready) return;
+    hipStreamCaptureMode cmode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&cmode);
+    for (size_t i = 0; i < c->retired.size(); ++i) {
+        auto& r = c->retired[i];
+        if (r.ev && hipEventQuery(r.ev) == hipSuccess) { (void)hipFree(r.ptr); r.ptr = nullptr; }
+    }
+    (void)hipGetLastError();
+    (void)hipThreadExchangeStreamCaptureMode(&cmode);
+    for (size_t i = 0; i < c->retired.size(); ++i)
+        if (!c->retired[i].ptr) drop_retired_event(c, i);
+    size_t keep = 0;
+    for (auto& r : c->retired)
+        if (r.ptr) c->retired[keep++] = r;
     c->retired.resize(keep);
 }
 
@@ -1106,7 +1214,9 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
         (void)hipFree(c->d_inv_lat);
         (void)hipDeviceSynchronize();  // user streams may still carry this context's kernels
         for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
-        for (auto& r : c->retired) (void)hipFree(r.ptr);
+        for (size_t i = 0; i < c->retired.size(); ++i) { (void)hipFree(c->retired[i].ptr); c->retired[i].ptr = nullptr; }
+        for (size_t i = 0; i < c->retired.size(); ++i) { drop_retired_event(c, i); c->retired[i].ev = nullptr; }
+        c->retired.clear();
         for (auto& kv : c->shifts) (void)hipFree(kv.second.d);
         if (c->pipe.ready) {
             (void)hipStreamDestroy(c->pipe.in);
@@ -2044,6 +2154,30 @@ int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, 
     return (int)hipGetLastError();
 }
 
+// Streams for callers without a HIP binding of their own (the Rust crate binds this library only): every `stream` argument of
+// this header is a hipStream_t, and these two make and release one (non-blocking with respect to the legacy default stream).
+int toyni_stream_create(void** stream, int device) {
+    if (!stream) return TOYNI_E_NULL;
+    *stream = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TOYNI_E_NO_DEVICE; }
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    if (device >= count) return TOYNI_E_RANGE;
+    DeviceGuard guard(device);
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return TOYNI_OK;
+}
+
+// Waits for the stream's work, then destroys it.  Scratch sets that contexts keep for this stream are released by their
+// own fences (see "Threading and streams" in the header); nothing needs to be told about the destruction.
+int toyni_stream_destroy(void* stream) {
+    if (!stream) return TOYNI_OK;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return (int)hipStreamDestroy((hipStream_t)stream);
+}
+
 int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (c) {
@@ -2059,9 +2193,10 @@ int toyni_ntt_ctx_trim(toyni_ntt_ctx* c) {
     TOYNI_CTX_LOCK(c);
     DeviceGuard guard(c->device);
     HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->scratch) retire_scratch(c, kv.second, kv.first, false);
+    for (auto& kv : c->scratch) { kv.second.dirty = false; retire_scratch(c, kv.second, kv.first, false); }
     c->scratch.clear();
-    for (auto& r : c->retired) (void)hipFree(r.ptr);
+    for (size_t i = 0; i < c->retired.size(); ++i) { (void)hipFree(c->retired[i].ptr); c->retired[i].ptr = nullptr; }
+    for (size_t i = 0; i < c->retired.size(); ++i) { drop_retired_event(c, i); c->retired[i].ev = nullptr; }
     c->retired.clear();
     return TOYNI_OK;
 }
