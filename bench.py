@@ -85,6 +85,12 @@ def cpu_baseline(log_n, seconds):
         o = p.communicate()[0].split()
         if len(o) >= 4:
             tot += 2 * int(o[2]) * n / float(o[3])
+    # the metric's other size: two repetitions of forward + inverse n = 2^24 (a repetition takes ~4 s on one core)
+    big = None
+    if log_n != 24:
+        breps, bel = run("ntt", 24, 4.5)
+        big = {"value": 2 * breps * (1 << 24) / bel, "unit": "elements/s", "cores": 1, "kind": "port",
+               "sample": f"{breps} x (forward + inverse) NTT n=2^24 on 1 thread, {bel:.1f} s"}
     fold_log = 20
     freps, fel = run("fold", fold_log, max(2.0, seconds / 3))
     fold_bytes = 6.0 * (1 << fold_log)          # algorithmic: 4 B read per input element + 2 B written
@@ -99,6 +105,7 @@ def cpu_baseline(log_n, seconds):
                  "elements_per_s": freps * (1 << fold_log) / fel,
                  "sample": f"{freps} x fri_fold of a 2^{fold_log} layer (xs = 7 w^i, one Fermat inversion per output as "
                            f"src/math/fri.rs:27-48), 1 thread, {fel:.1f} s; 6 B per input element"},
+        "n2^24": big,
         "rust_toolchain_present": shutil.which("cargo") is not None,
     }
 
@@ -326,6 +333,52 @@ class ToolsLib:
         self.lib.toyni_ntt_ctx_destroy(h)
 
 
+def profile_provenance(path):
+    """Which commit produced a committed profile, and whether the kernels have changed since: (short hash of the last commit that
+    touched `path`, True if toyni_amd/csrc has commits after it).  (None, None) outside a git checkout (the GPU box gets a snapshot
+    without .git: there profiles/PROVENANCE.json, written by tools/stamp_profiles.py at commit time, answers instead)."""
+    import subprocess
+    rel = os.path.relpath(path, ROOT)
+    try:
+        h = subprocess.run(["git", "log", "-1", "--format=%h", "--", rel], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
+        if h:
+            newer = subprocess.run(["git", "log", "--format=%h", f"{h}..HEAD", "--", "toyni_amd/csrc"], cwd=ROOT, capture_output=True, text=True,
+                                   timeout=20).stdout.split()
+            return h, bool(newer)
+    except (OSError, subprocess.SubprocessError):
+        pass
+    pj = os.path.join(ROOT, "profiles", "PROVENANCE.json")
+    if os.path.exists(pj):
+        ent = json.load(open(pj)).get(rel)
+        if ent:
+            return ent.get("commit"), ent.get("csrc_changed_since")
+    return None, None
+
+
+def stamp(src, path):
+    """`profiles/x.json (kernel)` -> the same string with the profile's commit; a warning on stderr when the kernels are newer."""
+    h, stale = profile_provenance(path)
+    if h is None:
+        return src + " [commit unknown]"
+    if stale:
+        print(f"bench.py: WARNING: {os.path.relpath(path, ROOT)} was measured at commit {h}; toyni_amd/csrc has changed since -- "
+              f"re-collect it (tools/collect_profiles.sh) before quoting roofline.traffic", file=sys.stderr)
+    return f"{src} [measured at commit {h}{'; csrc changed since: STALE' if stale else ''}]"
+
+
+def committed_fold_profile():
+    """rocprofv3 evidence of the fold kernel on a 2^27 layer (tools/collect_side_profiles.sh -> profiles/rNN_fold_stats.csv): average
+    launch duration and HBM bytes per launch of fri_fold_kernel<true, false>, newest round first."""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fold_stats.csv")), reverse=True):
+        for r in csv.DictReader(open(f)):
+            if "fri_fold_kernel<true, false>" in r["Name"] and r.get("hbm_bytes_largest_launch=(2*FETCH+WRITE)*1024"):
+                return {"rocprof_avg_ms": float(r["AverageNs"]) / 1e6, "rocprof_min_ms": float(r["MinNs"]) / 1e6, "launches": int(r["Calls"]),
+                        "traffic": float(r["hbm_bytes_largest_launch=(2*FETCH+WRITE)*1024"]), "file": f}
+    return None
+
+
 def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
     """HBM traffic and VALU instruction counts cannot be collected inside this process (rocprofv3 --pmc runs the command from
     outside): they are the COMMITTED rocprofv3 measurements of the same command (tools/collect_profiles.sh -> profiles/
@@ -342,7 +395,7 @@ def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
         if not kernels:
             continue
         k, v = max(kernels, key=lambda kv: kv[1].get("rocprof_avg_ns") or 0)
-        traffic, traffic_src = v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(tfile)} ({k.split('(')[0]})"
+        traffic, traffic_src = v["hbm_bytes_per_launch"], stamp(f"profiles/{os.path.basename(tfile)} ({k.split('(')[0]})", tfile)
         cfile = tfile.replace("_traffic", "_counters")
         if os.path.exists(cfile):
             cj = json.load(open(cfile))
@@ -602,8 +655,37 @@ def main():
                 o2 = torch.empty(1 << 26, dtype=torch.int32, device=dev)
                 t_fold = time_dev(lambda: toyni_amd.fri_fold_device(c27, big.data_ptr(), o2.data_ptr(), 1 << 27, 123456789, 7, stream=stream), 20)
                 extras["fri_fold_m2^27"] = {"us": t_fold * 1e6, "GBps": 6.0 * (1 << 27) / t_fold / 1e9, "frac_of_hbm_peak": 6.0 * (1 << 27) / t_fold / 1e9 / HBM_PEAK_GBPS}
+                # the same object the NTT has: the fold kernel against the HBM roofline, kernel duration from HIP events here and from the
+                # committed rocprofv3 run, HBM bytes from the committed FETCH_SIZE / WRITE_SIZE passes
+                fp = committed_fold_profile()
+                alg_fold = 6.0 * (1 << 27)
+                out["roofline_fold"] = {
+                    "bound": "hbm", "achieved": alg_fold / t_fold / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_fold / t_fold / 1e9 / HBM_PEAK_GBPS,
+                    "kernel": "fri_fold_kernel<true, false> (structured points, non-temporal), one 2^27 layer -> 2^26",
+                    "kernel_ms": t_fold * 1e3, "kernel_ms_source": "HIP events on the launch stream around 20 back-to-back launches (after one warm launch)",
+                    "algorithmic_bytes_per_launch": alg_fold,
+                    "traffic": fp["traffic"] if fp else None,
+                    "traffic_source": stamp(f"profiles/{os.path.basename(fp['file'])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)", fp["file"]) if fp else None,
+                    "rocprof_kernel_ms": fp["rocprof_avg_ms"] if fp else None, "rocprof_launches": fp["launches"] if fp else None,
+                }
                 del big, o2
                 c27.destroy()
+                # the reference's OWN signature fri_fold(evals, xs, beta) device-resident (explicit points: VERDICT r2 bench gap): one Fermat
+                # inversion chain per 4 outputs, so the bound is VALU, not HBM: 8 B per input element (4 evals + 2 xs read, 2 written)
+                xs24 = torch.randint(1, P, (nn // 2,), dtype=torch.int32, device=dev)
+                t_xs = time_dev(lambda: toyni_amd.fri_fold_xs_device(p1, xs24.data_ptr(), o.data_ptr(), nn, 123456789, stream=stream), 20)
+                # ~31 squarings + ~15 multiplies of the shared inversion chain per 4 outputs plus 3 products each to split it (Montgomery's
+                # trick) and the fold itself: ~70 mont_mul-class products per 4 outputs = 17.5 per output = 8.75 per input element, 5 VALU
+                # instructions each, against the 39.3 T lane-ops/s of that instruction class
+                xs_lane_ops = 8.75 * 5 + 10
+                extras["fri_fold_xs_m2^24"] = {
+                    "us": t_xs * 1e6, "GBps": 8.0 * nn / t_xs / 1e9, "frac_of_hbm_peak": 8.0 * nn / t_xs / 1e9 / HBM_PEAK_GBPS,
+                    "elements_per_s": nn / t_xs, "bound": "valu",
+                    "valu": {"lane_ops_per_input_element_estimate": xs_lane_ops, "achieved_Tops_estimate": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
+                             "frac_estimate": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
+                    "note": "toyni_fri_fold_xs_device on a 2^24 layer, explicit points resident in HBM; 8 B algorithmic per input element (4 evals + 2 xs "
+                            "read, 2 written); bound by the per-4-outputs Fermat inversion (src/math/fri.rs:38-40 inverts per element), not by HBM"}
+                del xs24
             # reference-shaped host-slice entry point (PCIe inclusive; never `value`)
             h = np.random.default_rng(1).integers(0, P, nn, dtype=np.uint64)
             c1.run_host(h, False)

@@ -297,6 +297,16 @@ int toyni_host_free(void* h_ptr);
 int toyni_free(void* d_ptr);
 int toyni_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int toyni_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+/* Stream-ordered copies and fills (asynchronous with pinned host memory; pageable host memory makes them block like HIP does). */
+int toyni_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int toyni_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int toyni_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, void* stream);
+int toyni_memset_async(void* d_ptr, int value, size_t bytes, void* stream);
+/* Merkle salts on the device: bytes of the ChaCha20 keystream (RFC 8439: 256-bit key, block counter from 0, 96-bit nonce =
+ * 0 || nonce as two little-endian words).  The reference draws 16 bytes per leaf from rand::thread_rng(), a ChaCha CSPRNG on the
+ * host (src/fibonacci.rs:341-343); this keeps ~130 MB of salts per 2^16-row proof off PCIe.  bytes: a multiple of 64; d_out
+ * 16-byte aligned.  The key is the caller's secret: draw it from the OS (getrandom) per proof. */
+int toyni_chacha20_fill_device(void* d_out, size_t bytes, const uint8_t key[32], uint64_t nonce, void* stream);
 int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream);
 int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, void* stream);
 /* Streams for host languages that bind only this library: device -1 = the current device; the stream is non-blocking with respect

@@ -11,7 +11,7 @@ from .ntt import (  # noqa: F401
     CudaBuffer, GpuBuffer, NttContext, PinnedArray, cuda_available, gpu_available, intt_cuda, intt_gpu, ntt_cuda, ntt_gpu,
     ntt_host_multi_gpu, ntt_slab_multi_gpu_device, ntt_slab_multi_gpu_host,
 )
-from .fri import fri_fold, fri_fold_device, fri_fold_ext, fri_fold_ext_device, fri_fold_layers_device  # noqa: F401
+from .fri import fri_fold, fri_fold_device, fri_fold_ext, fri_fold_ext_device, fri_fold_layers_device, fri_fold_xs_device  # noqa: F401
 from .domain import BabyBearDomain  # noqa: F401
 from .merkle import MerkleTree, merkle_commit_device  # noqa: F401
 from . import prover  # noqa: F401

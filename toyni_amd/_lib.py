@@ -115,6 +115,11 @@ SIGNATURES = {
     "toyni_host_free": (c_int, [c_void_p]),
     "toyni_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size]),
     "toyni_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size]),
+    "toyni_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "toyni_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "toyni_memcpy_d2d_async": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
+    "toyni_memset_async": (c_int, [c_void_p, c_int, c_size, c_void_p]),
+    "toyni_chacha20_fill_device": (c_int, [c_void_p, c_size, c_void_p, c_u64, c_void_p]),
     "toyni_narrow_u64_to_u32": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     "toyni_widen_u32_to_u64": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     "toyni_stream_create": (c_int, [ctypes.POINTER(c_void_p), c_int]),

@@ -22,6 +22,23 @@ TOYNI_HD uint32_t sha_xor3(uint32_t a, uint32_t b, uint32_t c) {
     return a ^ b ^ c;
 #endif
 }
+// Ch(e, f, g) = (e & f) ^ (~e & g) and Maj(a, b, c) as ONE v_bitop3_b32 each (truth tables 0xCA / 0xE8 with the operands as
+// 0xF0 / 0xCC / 0xAA): the compiler builds Maj from and / xor / bitop3 -- two instructions more per round, 255 of the 3 015 of a
+// node hash, on a chain whose length IS the latency of a tree level.
+TOYNI_HD uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)e, (int)f, (int)g, 0xCA);
+#else
+    return (e & f) ^ (~e & g);
+#endif
+}
+TOYNI_HD uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0xE8);
+#else
+    return (a & b) ^ (a & c) ^ (b & c);
+#endif
+}
 TOYNI_HD uint32_t sha_bswap(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24); }
 
 struct Sha256State { uint32_t h[8]; };
@@ -48,8 +65,8 @@ TOYNI_HD void sha256_compress(Sha256State& st, uint32_t (&w)[16]) {
             const uint32_t s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        const uint32_t t1 = h + sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
-        const uint32_t t2 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = h + sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25)) + sha_ch(e, f, g) + K[i] + w[i & 15];
+        const uint32_t t2 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22)) + sha_maj(a, b, c);
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     st.h[0] += a; st.h[1] += b; st.h[2] += c; st.h[3] += d; st.h[4] += e; st.h[5] += f; st.h[6] += g; st.h[7] += h;

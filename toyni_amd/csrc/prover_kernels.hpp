@@ -156,4 +156,31 @@ TOYNI_HD uint64_t merkle_sibling_row(uint64_t n, uint64_t index, uint32_t level,
     return off + sib;
 }
 
+
+// ---- salts: a ChaCha20 keystream (RFC 8439 2.3: constants | key | 32-bit block counter | 96-bit nonce, 20 rounds) ----
+// The reference salts every Merkle leaf with 16 bytes of `rand::thread_rng()` (src/fibonacci.rs:341-343), a ChaCha-based CSPRNG
+// on the host; a device-resident prover wants them where the leaves are hashed instead of 130 MB over PCIe per proof.  One block
+// = 64 bytes = the salts of four leaves.
+TOYNI_HD uint32_t chacha_rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+TOYNI_HD void chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      counter, nonce[0], nonce[1], nonce[2]};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
+#define TOYNI_QR(a, b, c, d)                                      \
+    x[a] += x[b]; x[d] = chacha_rotl(x[d] ^ x[a], 16);            \
+    x[c] += x[d]; x[b] = chacha_rotl(x[b] ^ x[c], 12);            \
+    x[a] += x[b]; x[d] = chacha_rotl(x[d] ^ x[a], 8);             \
+    x[c] += x[d]; x[b] = chacha_rotl(x[b] ^ x[c], 7)
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        TOYNI_QR(0, 4, 8, 12); TOYNI_QR(1, 5, 9, 13); TOYNI_QR(2, 6, 10, 14); TOYNI_QR(3, 7, 11, 15);
+        TOYNI_QR(0, 5, 10, 15); TOYNI_QR(1, 6, 11, 12); TOYNI_QR(2, 7, 8, 13); TOYNI_QR(3, 4, 9, 14);
+    }
+#undef TOYNI_QR
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];   // little-endian words = the keystream bytes on this (little-endian) target
+}
+
 }  // namespace toyni

@@ -347,6 +347,23 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f, const u
     }
 }
 
+// ---- salts (prover_kernels.hpp: chacha20_block) ----
+struct ChaChaArgs {
+    uint32_t key[8];
+    uint32_t nonce[3];
+    uint64_t blocks;
+    uint4* out;
+};
+__global__ void __launch_bounds__(256) chacha20_fill_kernel(const ChaChaArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < a.blocks; b += stride) {
+        uint32_t o[16];
+        chacha20_block(a.key, (uint32_t)b, a.nonce, o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.out[4 * b + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+}
+
 // ---- pointwise prover steps (prover_kernels.hpp) ----
 // constraint + quotient: 4 consecutive points per thread (16-byte accesses; the three trace reads of a point are B and 2B
 // words apart, B = blow-up, so they stay 16-byte aligned when B >= 4); 1 / Z_H per residue class in LDS
@@ -594,7 +611,11 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const Digest* __restr
 // All remaining levels of a tree whose current level has m <= MERKLE_TAIL digests, in ONE workgroup: the level lives in
 // LDS, each round halves it (odd rounds duplicate the last node) and is also written to global memory (the proofs need
 // every level).  Replaces ~log2(m) tiny launches per tree -- the FRI layers of a proof are mostly trees this small.
+// Round 3: 512 threads, ONE node per thread (round 2: 256 threads, two nodes per thread at the 512-node level).  A 2048-digest tail
+// (1024 threads) was measured and is slower: the 1024-node level then runs four waves per SIMD on one CU where the level kernel
+// spreads it over four CUs (2^11-leaf FRI round 118 against 106 us, profiles/r03_fri_rounds_*.txt).
 constexpr uint32_t MERKLE_TAIL = 1024;
+constexpr uint32_t MERKLE_TAIL_T = 512;
 // `notify` (optional): 9 words of pinned host memory -- the root, then a sequence number stored with system-scope release once
 // the root is there.  The host polls that word instead of paying a copy and a stream synchronisation for 32 bytes.
 __device__ inline void merkle_notify(const Digest& root, uint32_t* notify, uint32_t seq) {
@@ -606,31 +627,34 @@ __device__ inline void merkle_notify(const Digest& root, uint32_t* notify, uint3
 __global__ void merkle_notify_kernel(const Digest* __restrict__ root, uint32_t* notify, uint32_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) merkle_notify(*root, notify, seq);
 }
-__global__ void __launch_bounds__(256) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m,
-                                                          uint32_t* notify, uint32_t seq) {
-    __shared__ Digest lvl[MERKLE_TAIL];
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
-    __syncthreads();
+// the levels above `lvl[0 .. m)` (already in LDS and in global memory), one workgroup; m <= MERKLE_TAIL, so a level above has at
+// most MERKLE_TAIL / 2 = blockDim nodes: one per thread, and the chain of dependent hashes is as short as the tree is deep
+__device__ inline void merkle_tail_levels(Digest* lvl, Digest* __restrict__ next, uint32_t m, uint32_t* notify, uint32_t seq) {
     while (m > 1) {
-        const uint32_t up = (m + 1) / 2;
-        Digest mine[MERKLE_TAIL / 2 / 256];
-        uint32_t cnt = 0;
-        for (uint32_t i = threadIdx.x; i < up; i += blockDim.x) {
+        const uint32_t up = (m + 1) / 2, i = threadIdx.x;
+        Digest mine;
+        if (i < up) {
             const Digest l = lvl[2 * i];
             const Digest r = (2 * i + 1 < m) ? lvl[2 * i + 1] : l;
-            mine[cnt++] = merkle_node(l, r);
+            mine = merkle_node(l, r);
         }
         __syncthreads();  // every read of the old level is done
-        cnt = 0;
-        for (uint32_t i = threadIdx.x; i < up; i += blockDim.x) {
-            lvl[i] = mine[cnt];
-            next[i] = mine[cnt++];
+        if (i < up) {
+            lvl[i] = mine;
+            next[i] = mine;
         }
         __syncthreads();
         next += up;
         m = up;
     }
     if (notify && threadIdx.x == 0) merkle_notify(lvl[0], notify, seq);
+}
+__global__ void __launch_bounds__(MERKLE_TAIL_T) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m,
+                                                                    uint32_t* notify, uint32_t seq) {
+    __shared__ Digest lvl[MERKLE_TAIL];
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
+    __syncthreads();
+    merkle_tail_levels(lvl, next, m, notify, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1675,13 +1699,11 @@ int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, ui
 }
 
 // ---- FRI fold ----
-static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s,
-                        const uint8_t* d_salts = nullptr, uint8_t* d_leaves = nullptr) {
+static int fold_args(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, FoldArgs& f) {
     if (m % 2) return TOYNI_E_ODD_LENGTH;
-    if (m == 0) return TOYNI_OK;
     if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
     if (x0 == 0 || x0 >= BB_P || beta >= BB_P) return x0 == 0 ? TOYNI_E_ZERO_INVERSE : TOYNI_E_RANGE;
-    FoldArgs f{};
+    f = FoldArgs{};
     f.evals = d_evals;
     f.out = d_out;
     f.inv_lo = c->d_inv + c->plan.dom_lo_off;
@@ -1690,6 +1712,15 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     f.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
+    return TOYNI_OK;
+}
+
+static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s,
+                        const uint8_t* d_salts = nullptr, uint8_t* d_leaves = nullptr) {
+    if (m == 0) return TOYNI_OK;
+    FoldArgs f;
+    int rc = fold_args(c, d_evals, d_out, m, beta, x0, f);
+    if (rc) return rc;
     const size_t work = (d_leaves || (f.half & 3)) ? f.half : f.half / 4;
     const uint4* no_salts = nullptr;
     Digest* no_leaves = nullptr;
@@ -1702,6 +1733,20 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
         hipLaunchKernelGGL((fri_fold_kernel<false, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     }
     return (int)hipGetLastError();
+}
+
+static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint32_t* notify = nullptr, uint32_t seq = 0);
+
+// One protocol round: fold (+ leaf hashes in the same sweep) and the node levels of the folded layer's tree (+ the root's
+// notification).  Round 3 built the round of a small layer (<= 2^11 leaves) as ONE single-workgroup launch -- fold, leaves, every
+// level, notify -- and measured it against these two launches: 41.8-118 us against 42.6-106 us per round for
+// 16 ... 2048 leaves (profiles/r03_fri_rounds_fused_small.txt / _two_launch.txt): nothing, because a small round is not launch-bound
+// but a chain of dependent SHA-256 compressions (3.3 us each on one wave: ~1 500 instructions at 5 cycles); not kept.
+static int enqueue_fold_commit(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, hipStream_t s,
+                               const uint8_t* d_salts, uint8_t* d_levels, uint32_t* notify, uint32_t seq) {
+    int rc = enqueue_fold(c, d_evals, d_out, m, beta, x0, s, d_salts, d_levels);
+    if (rc) return rc;
+    return enqueue_merkle_upper(d_levels, m / 2, s, notify, seq);
 }
 
 int toyni_fri_fold_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, void* stream) {
@@ -1872,8 +1917,6 @@ size_t toyni_merkle_total_digests(size_t n) {
 }
 
 // levels above the leaf hashes (already in d_levels[0 .. n))
-static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint32_t* notify = nullptr, uint32_t seq = 0);
-
 int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts, size_t n, uint8_t* d_levels, void* stream) {
     if (!d_values || !d_levels) return TOYNI_E_NULL;
     if (n == 0) return TOYNI_OK;
@@ -1893,7 +1936,7 @@ static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint
         cur += m;
         m = up;
     }
-    if (m > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(256), 0, s, (const Digest*)cur, cur + m, (uint32_t)m, notify, seq);
+    if (m > 1) hipLaunchKernelGGL(merkle_tail_kernel, dim3(1), dim3(MERKLE_TAIL_T), 0, s, (const Digest*)cur, cur + m, (uint32_t)m, notify, seq);
     else if (notify) hipLaunchKernelGGL(merkle_notify_kernel, dim3(1), dim3(64), 0, s, (const Digest*)cur, notify, seq);  // a one-leaf tree: the leaf hash is the root
     return (int)hipGetLastError();
 }
@@ -1934,9 +1977,7 @@ int toyni_fri_fold_commit_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint
     TOYNI_CTX_LOCK(c);
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
-    int rc = enqueue_fold(c, d_evals, d_out, m, beta, x0, s, d_salts, d_levels);
-    if (rc) return rc;
-    return enqueue_merkle_upper(d_levels, m / 2, s);
+    return enqueue_fold_commit(c, d_evals, d_out, m, beta, x0, s, d_salts, d_levels, nullptr, 0);
 }
 
 // spin on a word of pinned host memory until the device has stored `want` there (false after `seconds`)
@@ -1998,9 +2039,8 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
         const size_t half = m >> 1;
         const bool last = half == final_size;
         const size_t digests = toyni_merkle_total_digests(half);
-        if ((rc = enqueue_fold(c, cur, out, m, beta, x, s, last ? nullptr : salts, levels))) return rc;
         const uint32_t seq = ++c->root_seq ? c->root_seq : ++c->root_seq;   // never 0
-        if ((rc = enqueue_merkle_upper(levels, half, s, c->d_root_notify, seq))) return rc;
+        if ((rc = enqueue_fold_commit(c, cur, out, m, beta, x, s, last ? nullptr : salts, levels, c->d_root_notify, seq))) return rc;
         // The tree's last kernel writes the root and then `seq` into pinned host memory; everything enqueued before it on `s` has
         // completed by then (stream order).  Polling costs ~2 us where a 32-byte copy plus a stream synchronisation costs ~16.
         if (!poll_until(flag, seq, 2.0)) {
@@ -2139,6 +2179,36 @@ int toyni_host_alloc(void** h_ptr, size_t bytes) { return h_ptr ? (int)hipHostMa
 int toyni_host_free(void* h_ptr) { return (int)hipHostFree(h_ptr); }
 int toyni_memcpy_h2d(void* d, const void* h, size_t bytes) { return (int)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); }
 int toyni_memcpy_d2h(void* h, const void* d, size_t bytes) { return (int)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost); }
+// stream-ordered forms: what a device-resident pipeline in a host language without a HIP binding needs between the calls of this
+// header (csrc/host/fib_prover.hpp is written against exactly these)
+int toyni_memcpy_h2d_async(void* d, const void* h, size_t bytes, void* stream) {
+    return bytes ? (int)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) : TOYNI_OK;
+}
+int toyni_memcpy_d2h_async(void* h, const void* d, size_t bytes, void* stream) {
+    return bytes ? (int)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) : TOYNI_OK;
+}
+int toyni_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+    return bytes ? (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) : TOYNI_OK;
+}
+int toyni_memset_async(void* d, int value, size_t bytes, void* stream) {
+    return bytes ? (int)hipMemsetAsync(d, value, bytes, (hipStream_t)stream) : TOYNI_OK;
+}
+
+int toyni_chacha20_fill_device(void* d_out, size_t bytes, const uint8_t key[32], uint64_t nonce, void* stream) {
+    if (!d_out || !key) return TOYNI_E_NULL;
+    if (((uintptr_t)d_out & 15) || (bytes & 63)) return TOYNI_E_RANGE;   // whole 64-byte blocks, 16-byte stores
+    if (bytes == 0) return TOYNI_OK;
+    if (bytes / 64 > 0xFFFFFFFFull) return TOYNI_E_RANGE;               // RFC 8439's 32-bit block counter
+    ChaChaArgs a{};
+    std::memcpy(a.key, key, 32);
+    a.nonce[0] = 0u;
+    a.nonce[1] = (uint32_t)nonce;
+    a.nonce[2] = (uint32_t)(nonce >> 32);
+    a.blocks = bytes / 64;
+    a.out = reinterpret_cast<uint4*>(d_out);
+    hipLaunchKernelGGL(chacha20_fill_kernel, dim3(grid_for(a.blocks)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
 
 int toyni_narrow_u64_to_u32(const uint64_t* d_in, uint32_t* d_out, size_t count, void* stream) {
     if (!d_in || !d_out) return TOYNI_E_NULL;

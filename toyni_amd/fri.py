@@ -23,6 +23,12 @@ def fri_fold_device(ctx, d_evals: int, d_out: int, m: int, beta: int, x0: int, s
     check(lib.toyni_fri_fold_device(ctx.handle, d_evals, d_out, m, beta, x0, stream or None), "GPU FRI fold failed")
 
 
+def fri_fold_xs_device(d_evals: int, d_xs: int, d_out: int, m: int, beta: int, stream: int = 0) -> None:
+    """Device-resident form of the reference's own signature fri_fold(evals, xs, beta) (src/math/fri.rs:27-48): explicit points,
+    only xs[0 .. m/2) is read (packed u32 pointers)."""
+    check(lib.toyni_fri_fold_xs_device(d_evals, d_xs, d_out, m, beta, stream or None), "GPU FRI fold (explicit points) failed")
+
+
 def fri_fold_layers_device(ctx, d_evals: int, d_layers: int, betas, shift: int, stream: int = 0) -> None:
     """The prover's fold loop: len(betas) layers of a size-ctx.n codeword on shift * <w_n>, back to back in d_layers."""
     b = np.ascontiguousarray(betas, dtype=np.uint32)
