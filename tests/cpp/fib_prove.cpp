@@ -87,9 +87,11 @@ int main(int argc, char** argv) {
     if (out_path && !write_proof(out_path, proof)) { std::fprintf(stderr, "cannot write %s\n", out_path); return 1; }
     std::printf("{\"gpu\": true, \"trace_len\": %zu, \"lde_size\": %zu, \"folds\": %zu, \"final_layer_size\": %zu, \"ms\": %s, "
                 "\"phases\": {\"1_interpolate_mask_lde_commit\": %.4f, \"2_constraint_quotient_commit\": %.4f, \"3_transcript_ood\": %.4f, \"5_deep\": %.4f, "
-                "\"6_fri_fold_commit\": %.4f, \"7_queries\": %.4f}, \"proof_bytes\": %zu}\n",
+                "\"6_fri_fold_commit\": %.4f, \"7_queries\": %.4f}, \"proof_bytes\": %zu, "
+                "\"pcie\": {\"h2d_bytes\": %zu, \"d2h_bytes\": %zu, \"h2d_copies\": %zu, \"d2h_copies\": %zu, \"pinned_root_writes\": %zu}}\n",
                 proof.trace_len, proof.lde_size, prover.folds(), prover.final_layer_size(), ms.c_str(), pt.interpolate_lde_commit, pt.quotient_commit,
                 pt.transcript_ood, pt.deep, pt.fri, pt.queries,
-                proof.opening_records.size() + 32 * (2 + proof.fri_commitments.size()) + 4 * (4 + proof.fri_final_layer.size()));
+                proof.opening_records.size() + 32 * (2 + proof.fri_commitments.size()) + 4 * (4 + proof.fri_final_layer.size()),
+                prover.traffic().h2d_bytes, prover.traffic().d2h_bytes, prover.traffic().h2d_copies, prover.traffic().d2h_copies, prover.traffic().pinned_root_writes);
     return 0;
 }

@@ -270,6 +270,48 @@ static void test_merkle(size_t n, bool salted) {
     CHECK(std::memcmp(lv.data(), want.data(), 32 * total) == 0, "merkle n=%zu salted=%d", n, (int)salted);
 }
 
+// The two-wave node hash (merkle_kernels.hpp, "a node hash on TWO waves"): the phase bodies run in the kernel's order -- helper A,
+// main A, (barrier), helper B, main B, (barrier), main C -- for 64 lanes sharing one hand-over area, against merkle_node; and the
+// compile-time table of block 2's schedule against a direct expansion.
+static void test_merkle_coop() {
+    static const ShaB2Table b2 = make_sha_b2_table();
+    std::vector<uint32_t> sched(COOP_SCHED_WORDS, 0xDEADBEEFu);
+    Digest l[64], r[64];
+    uint64_t seed = 0xC00Full;
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            seed = seed * 6364136223846793005ull + 1442695040888963407ull; l[lane].m[j] = (uint32_t)(seed >> 32);
+            seed = seed * 6364136223846793005ull + 1442695040888963407ull; r[lane].m[j] = (uint32_t)(seed >> 32);
+        }
+    r[7] = l[7];                                     // an odd level's duplicated last node
+    for (int j = 0; j < 8; ++j) r[9].m[j] = 0xFFFFFFFFu;
+    uint32_t wh[64][16], wm[64][16], last[64];
+    ShaRegs st[64];
+    for (uint32_t lane = 0; lane < 64; ++lane) {     // phase A
+        uint32_t dummy;
+        node_block1(l[lane], r[lane], wh[lane], dummy);
+        coop_helper_schedule<16, 24>(wh[lane], sched.data(), lane);
+        node_block1(l[lane], r[lane], wm[lane], last[lane]);
+        coop_main_first16(st[lane], wm[lane]);
+    }
+    for (uint32_t lane = 0; lane < 64; ++lane) {     // phase B
+        coop_helper_schedule<40, 24>(wh[lane], sched.data(), lane);
+        coop_main_rounds<16>(st[lane], sched.data(), lane);
+    }
+    size_t bad = 0;
+    for (uint32_t lane = 0; lane < 64; ++lane) {     // phase C
+        coop_main_rounds<40>(st[lane], sched.data(), lane);
+        uint32_t kw2[64];
+        for (int i = 0; i < 64; ++i) kw2[i] = b2.kw[i][last[lane]];
+        const Digest got = coop_main_finish(st[lane], kw2);
+        const Digest want = merkle_node(l[lane], r[lane]);
+        bad += std::memcmp(&got, &want, sizeof(Digest)) != 0;
+    }
+    CHECK(bad == 0, "two-wave node hash: %zu of 64 digests differ from merkle_node", bad);
+    for (size_t k = 0; k < COOP_SCHED_WORDS; ++k) bad += sched[k] == 0xDEADBEEFu;
+    CHECK(bad == 0, "two-wave node hash: %zu hand-over words never written", bad);
+}
+
 // Low-degree extension: compact input (n >> lde_log words per transform), zero padding implied, coset shift fused
 static void test_lde(int log_n, uint64_t batch, int lde_log, uint32_t shift) {
     NttPlan plan;
@@ -555,6 +597,7 @@ int main(int argc, char** argv) {
     test_fold(1, 0, 7);
     test_fold(6, 2, 1);
     for (size_t n : {1, 2, 3, 4, 5, 8, 100, 1024}) { test_merkle(n, false); test_merkle(n, true); }
+    test_merkle_coop();
     test_prover_steps(6, 2, 7);
     test_prover_steps(9, 5, 7);
     test_prover_steps(8, 3, 1234567);

@@ -183,6 +183,11 @@ class Prover {
         };
         const uint32_t g = root_of_unity(log_n_);
         uint32_t* hp = reinterpret_cast<uint32_t*>(h_pinned_);
+        traffic_ = Traffic{};
+        // every byte this proof moves over PCIe goes through these two (and the 32-byte roots the commit phase reads from pinned
+        // memory): the totals are reported next to rocprofv3's --memory-copy-trace of the same program (profiles/r03_fib_prove_memcopy.txt)
+        auto up = [&](void* d, const void* h, size_t bytes) { traffic_.h2d_bytes += bytes; ++traffic_.h2d_copies; return toyni_memcpy_h2d_async(d, h, bytes, s); };
+        auto down = [&](void* h, const void* d, size_t bytes) { traffic_.d2h_bytes += bytes; ++traffic_.d2h_copies; return toyni_memcpy_d2h_async(h, d, bytes, s); };
         // every salt of the proof in one keystream: 3 LDE-size trees + the salted FRI layers (16 bytes per leaf, :341-343)
         TOYNI_FIB_TRY(toyni_chacha20_fill_device(d_salts_, salt_bytes_, key, 0, s), "salts");
         const uint8_t* salts_trace = d_salts_;
@@ -193,25 +198,38 @@ class Prover {
         // ---- 1. trace polynomial + masking (:110-121): T_hat = T + (x^n - 1) R; LDE on the coset; commit ----
         TOYNI_FIB_TRY(toyni_memset_async(d_compact_, 0, (size_t)4 << log_c_, s), "clear");
         std::memcpy(hp, trace, 4 * n_);
-        TOYNI_FIB_TRY(toyni_memcpy_h2d_async(d_compact_, hp, 4 * n_, s), "trace upload");
+        TOYNI_FIB_TRY(up(d_compact_, hp, 4 * n_), "trace upload");
         TOYNI_FIB_TRY(toyni_ntt_device(ctx_n_, d_compact_, d_compact_, 1, 1, s), "interpolation (INTT)");
-        uint32_t* low = hp + n_;                       // staging for the MASK_DEGREE lowest coefficients
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(low, d_compact_, 4 * MASK_DEGREE, s), "coefficients down");
+        // masking on the host: only the coefficients it touches cross PCIe.  T_hat = T - R + x^n R touches [0, MASK_DEGREE) and
+        // [n, n + MASK_DEGREE); the words above n are zero after the size-n INTT.  Short traces (n < MASK_DEGREE, e.g. the
+        // reference's own trace_len 64) have the two ranges overlap: they are staged as one range [0, n + MASK_DEGREE).
+        const bool overlap = n_ < MASK_DEGREE;
+        const size_t nlow = overlap ? n_ : MASK_DEGREE;            // coefficients that can be non-zero among the first MASK_DEGREE
+        uint32_t* stage = hp + n_;                                 // [0, MASK_DEGREE) then [n, n + MASK_DEGREE), or the one merged range
+        const size_t stage_words = overlap ? n_ + MASK_DEGREE : 2 * (size_t)MASK_DEGREE;
+        std::memset(stage, 0, 4 * stage_words);
+        TOYNI_FIB_TRY(down(stage, d_compact_, 4 * nlow), "coefficients down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
-        uint32_t* high = low + MASK_DEGREE;
         {
             uint32_t ks[16];
             const uint32_t nonce[3] = {0u, 1u, 0u};   // nonce 1: the mask's keystream (nonce 0 is the salts')
+            const auto kw = key_words(key);
+            uint32_t* minus = stage;                                      // - R at x^i
+            uint32_t* plus = overlap ? stage + n_ : stage + MASK_DEGREE;  // + R at x^(n + i)
             for (unsigned i = 0; i < MASK_DEGREE; ++i) {
-                if (i % 8 == 0) chacha20_block(reinterpret_cast<const uint32_t*>(key_words(key).data()), i / 8, nonce, ks);
+                if (i % 8 == 0) chacha20_block(kw.data(), i / 8, nonce, ks);
                 const uint64_t v = (uint64_t)ks[2 * (i % 8)] | (uint64_t)ks[2 * (i % 8) + 1] << 32;
                 const uint32_t r = (uint32_t)(v % P);
-                low[i] = submod(low[i], r);            // - R
-                high[i] = r;                           // + x^n R   (the words above n were zero: the INTT touches n of them)
+                minus[i] = submod(minus[i], r);
+                plus[i] = addmod(plus[i], r);
             }
         }
-        TOYNI_FIB_TRY(toyni_memcpy_h2d_async(d_compact_, low, 4 * MASK_DEGREE, s), "masked coefficients up");
-        TOYNI_FIB_TRY(toyni_memcpy_h2d_async(d_compact_ + n_, high, 4 * MASK_DEGREE, s), "masked coefficients up");
+        if (overlap) {
+            TOYNI_FIB_TRY(up(d_compact_, stage, 4 * (n_ + MASK_DEGREE)), "masked coefficients up");
+        } else {
+            TOYNI_FIB_TRY(up(d_compact_, stage, 4 * MASK_DEGREE), "masked coefficients up");
+            TOYNI_FIB_TRY(up(d_compact_ + n_, stage + MASK_DEGREE, 4 * MASK_DEGREE), "masked coefficients up");
+        }
         const size_t ncoef_t = n_ + MASK_DEGREE;       // trace_poly = compact[0 .. ncoef_t)
         TOYNI_FIB_TRY(toyni_lde_device(ctx_N_, d_compact_, d_trace_lde_, 1, log_N_ - log_c_, COSET_SHIFT, s), "LDE");
         TOYNI_FIB_TRY(toyni_merkle_commit_device(d_trace_lde_, salts_trace, N_, d_trace_tree_, s), "trace commitment");
@@ -223,9 +241,9 @@ class Prover {
         TOYNI_FIB_TRY(toyni_coset_ntt_device(ctx_N_, d_q_, d_qpoly_, 1, COSET_SHIFT, 1, s), "ifft (q_poly)");      // :151
         TOYNI_FIB_TRY(toyni_merkle_commit_device(d_q_, salts_quot, N_, d_quot_tree_, s), "quotient commitment");
         const size_t root_off = (toyni_merkle_total_digests(N_) - 1) * 32;
-        uint8_t* roots = reinterpret_cast<uint8_t*>(high + MASK_DEGREE);
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(roots, d_trace_tree_ + root_off, 32, s), "root down");
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(roots + 32, d_quot_tree_ + root_off, 32, s), "root down");
+        uint8_t* roots = reinterpret_cast<uint8_t*>(stage + stage_words);
+        TOYNI_FIB_TRY(down(roots, d_trace_tree_ + root_off, 32), "root down");
+        TOYNI_FIB_TRY(down(roots + 32, d_quot_tree_ + root_off, 32), "root down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
         std::memcpy(proof.trace_commitment.data(), roots, 32);
         std::memcpy(proof.quotient_commitment.data(), roots + 32, 32);
@@ -244,7 +262,7 @@ class Prover {
         TOYNI_FIB_TRY(toyni_poly_eval_device(ctx_N_, d_compact_, ncoef_t, pts, 3, d_ood_, s), "OOD evaluations of T");
         TOYNI_FIB_TRY(toyni_poly_eval_device(ctx_N_, d_qpoly_, N_, pts, 1, d_ood_ + 3, s), "OOD evaluation of Q");
         uint32_t* ood = reinterpret_cast<uint32_t*>(roots + 64);
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(ood, d_ood_, 16, s), "OOD values down");
+        TOYNI_FIB_TRY(down(ood, d_ood_, 16), "OOD values down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
         proof.t_z = ood[0]; proof.t_gz = ood[1]; proof.t_ggz = ood[2]; proof.q_z = ood[3];
         {
@@ -261,7 +279,7 @@ class Prover {
 
         // ---- 6. FRI (:200-247): layer 0's tree here, then the whole fold loop in one call with the transcript behind a callback ----
         TOYNI_FIB_TRY(toyni_merkle_commit_device(d_deep_, salts_deep, N_, d_deep_tree_, s), "DEEP commitment");
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(roots, d_deep_tree_ + root_off, 32, s), "root down");
+        TOYNI_FIB_TRY(down(roots, d_deep_tree_ + root_off, 32), "root down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
         proof.fri_commitments.clear();
         proof.fri_commitments.emplace_back();
@@ -284,8 +302,10 @@ class Prover {
             &cb, d_layers_, d_fri_trees_, nullptr, &rounds, s);
         if (st) return std::string("FRI commit phase: ") + toyni_error_string(st);
         if (rounds != sizes_.size()) return "FRI round count mismatch";
+        traffic_.d2h_bytes += 32 * (size_t)rounds;   // the per-round roots: written by the device into pinned host memory, no copy call
+        traffic_.pinned_root_writes += rounds;
         proof.fri_final_layer.assign(final_size_, 0);
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(ood, d_layers_ + (fri_words_ - final_size_), 4 * final_size_, s), "final layer down");
+        TOYNI_FIB_TRY(down(ood, d_layers_ + (fri_words_ - final_size_), 4 * final_size_), "final layer down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
         std::memcpy(proof.fri_final_layer.data(), ood, 4 * final_size_);
         if (times) lap(times->fri);
@@ -317,7 +337,7 @@ class Prover {
             size_t o = 0;
             for (auto& gr : proof.opening_groups) { std::memcpy(hp + o, gr.indices.data(), 4 * gr.indices.size()); o += gr.indices.size(); }
         }
-        TOYNI_FIB_TRY(toyni_memcpy_h2d_async(d_idx_, hp, 4 * nidx, s), "query positions up");
+        TOYNI_FIB_TRY(up(d_idx_, hp, 4 * nidx), "query positions up");
         {
             size_t io = 0, bo = 0, lo = 0, dlo = 0, slo = 0;
             for (size_t k = 0; k < proof.opening_groups.size(); ++k) {
@@ -338,7 +358,7 @@ class Prover {
             }
         }
         proof.opening_records.resize(nbytes);
-        TOYNI_FIB_TRY(toyni_memcpy_d2h_async(h_pinned_, d_records_, nbytes, s), "opening records down");
+        TOYNI_FIB_TRY(down(h_pinned_, d_records_, nbytes), "opening records down");
         TOYNI_FIB_TRY(toyni_stream_synchronize(nullptr, s), "sync");
         std::memcpy(proof.opening_records.data(), h_pinned_, nbytes);
         if (times) lap(times->queries);
@@ -348,6 +368,8 @@ class Prover {
 #undef TOYNI_FIB_TRY
     }
 
+    struct Traffic { size_t h2d_bytes = 0, d2h_bytes = 0, h2d_copies = 0, d2h_copies = 0, pinned_root_writes = 0; };
+    const Traffic& traffic() const { return traffic_; }   // PCIe traffic of the last proof
     size_t folds() const { return sizes_.size(); }
     size_t final_layer_size() const { return final_size_; }
 
@@ -360,7 +382,7 @@ class Prover {
     size_t max_openings() const { return NUM_QUERIES * (3 + 1 + 2 + 2 * (sizes_.empty() ? 0 : sizes_.size() - 1)); }
     size_t max_record_bytes() const { return max_openings() * toyni_merkle_open_record_bytes(N_); }
     size_t pinned_bytes() const {
-        size_t b = 4 * n_ + 4 * 2 * MASK_DEGREE + 64 + 16 + 4 * (final_size_ > 4 ? final_size_ : 4) + 64;
+        size_t b = 4 * n_ + 4 * (n_ + 2 * MASK_DEGREE) + 64 + 16 + 4 * (final_size_ > 4 ? final_size_ : 4) + 64;
         if (b < max_record_bytes()) b = max_record_bytes();
         if (b < 4 * max_openings()) b = 4 * max_openings();
         return b;
@@ -379,6 +401,7 @@ class Prover {
     unsigned log_n_ = 0, log_N_ = 0, log_c_ = 0;
     int device_;
     bool ready_ = false;
+    Traffic traffic_;
     std::vector<size_t> sizes_;       // folded layer sizes N/2 ... final_size
     toyni_ntt_ctx *ctx_n_ = nullptr, *ctx_N_ = nullptr;
     void* stream_ = nullptr;

@@ -131,4 +131,105 @@ TOYNI_HD Digest merkle_node(const Digest& left, const Digest& right) {
     return digest_of(st);
 }
 
+
+// ---- a node hash on TWO waves (round 3) ------------------------------------------------------------------------------------
+// A tree level with few nodes is pure latency: one thread's node hash is ~3 000 dependent-ish instructions, and a lone wave issues one
+// instruction per 5 cycles whatever the other 255 CUs do -- 6.5 us per level, 200-odd levels per proof (a 2^16-row Fibonacci proof
+// spends 83 % of its time in these kernels).  What CAN be taken off the critical wave is everything that does not depend on the
+// running state:
+//   * block 1's message schedule W[16..63] (10 of the 26 instructions of a round): a HELPER wave on another SIMD computes it from
+//     the same 16 message words and hands K[i] + W[i] over through LDS, a third of a block ahead of the rounds that consume it;
+//   * block 2's schedule: its message is one data byte (the last byte of the right child) followed by constants, so K[i] + W[i] is a
+//     table of 64 x 256 words (SHA_B2, built at compile time), gathered by the main wave while block 1 runs.
+// The main wave is left with the 128 round functions: ~2 100 instructions instead of ~3 000.  Same digests, bit for bit (tests/emu
+// steps the phase bodies below against merkle_node; the GPU tests compare whole trees with hashlib).
+// Phases (a workgroup-wide barrier between them; both roles execute every barrier):
+//   A  main: rounds 0..15 of block 1        helper: K + W[16..39] -> LDS
+//   B  main: rounds 16..39 (W from LDS)     helper: K + W[40..63] -> LDS
+//   C  main: rounds 40..63, block 2 from the table, digest
+constexpr uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// K[i] + W[i] of a node hash's SECOND block for each value of its one data byte: block = byte 80 00 .. 00 | length 520 bits
+struct ShaB2Table { uint32_t kw[64][256]; };
+constexpr uint32_t cx_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+constexpr ShaB2Table make_sha_b2_table() {
+    ShaB2Table t{};
+    for (uint32_t byte = 0; byte < 256; ++byte) {
+        uint32_t w[64] = {};
+        w[0] = (byte << 24) | 0x00800000u;
+        w[15] = 520u;
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = cx_rotr(w[i - 15], 7) ^ cx_rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = cx_rotr(w[i - 2], 17) ^ cx_rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        for (int i = 0; i < 64; ++i) t.kw[i][byte] = SHA_K[i] + w[i];
+    }
+    return t;
+}
+
+struct ShaRegs { uint32_t a, b, c, d, e, f, g, h; };
+TOYNI_HD void sha_round(ShaRegs& s, uint32_t kw) {
+    const uint32_t t1 = s.h + sha_xor3(sha_rotr(s.e, 6), sha_rotr(s.e, 11), sha_rotr(s.e, 25)) + sha_ch(s.e, s.f, s.g) + kw;
+    const uint32_t t2 = sha_xor3(sha_rotr(s.a, 2), sha_rotr(s.a, 13), sha_rotr(s.a, 22)) + sha_maj(s.a, s.b, s.c);
+    s.h = s.g; s.g = s.f; s.f = s.e; s.e = s.d + t1; s.d = s.c; s.c = s.b; s.b = s.a; s.a = t1 + t2;
+}
+// the 16 message words of a node's first block: 01 || left || right[0..30]; `last` = the byte left over for block 2
+TOYNI_HD void node_block1(const Digest& left, const Digest& right, uint32_t (&w)[16], uint32_t& last) {
+    uint32_t d[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d[j] = sha_bswap(left.m[j]); d[8 + j] = sha_bswap(right.m[j]); }
+    w[0] = 0x01000000u | (d[0] >> 8);
+#pragma unroll
+    for (int j = 1; j < 16; ++j) w[j] = (d[j - 1] << 24) | (d[j] >> 8);
+    last = d[15] & 0xFFu;
+}
+// LDS hand-over area of one main / helper pair: word (i - 16) * 64 + lane holds K[i] + W[i] of block 1, i = 16 .. 63
+constexpr uint32_t COOP_SCHED_WORDS = 48u * 64u;
+
+// helper, phases A (FIRST = 16, COUNT = 24) and B (FIRST = 40): W ring in registers across the two calls
+template <int FIRST, int COUNT>
+TOYNI_HD void coop_helper_schedule(uint32_t (&w)[16], uint32_t* sched, uint32_t lane) {
+#pragma unroll
+    for (int i = FIRST; i < FIRST + COUNT; ++i) {
+        const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        const uint32_t s0 = sha_xor3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+        const uint32_t s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
+        w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        sched[(uint32_t)(i - 16) * 64u + lane] = SHA_K[i] + w[i & 15];
+    }
+}
+// main, phase A: rounds 0 .. 15 straight from the message words
+TOYNI_HD void coop_main_first16(ShaRegs& s, const uint32_t (&w)[16]) {
+    const Sha256State iv = sha256_init();
+    s = ShaRegs{iv.h[0], iv.h[1], iv.h[2], iv.h[3], iv.h[4], iv.h[5], iv.h[6], iv.h[7]};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sha_round(s, SHA_K[i] + w[i]);
+}
+// main, phases B (FIRST = 16) and C (FIRST = 40): 24 rounds each, K + W from the pair's LDS area
+template <int FIRST>
+TOYNI_HD void coop_main_rounds(ShaRegs& s, const uint32_t* sched, uint32_t lane) {
+    uint32_t kw[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) kw[i] = sched[(uint32_t)(FIRST - 16 + i) * 64u + lane];   // all issued up front: one LDS latency, not 24
+#pragma unroll
+    for (int i = 0; i < 24; ++i) sha_round(s, kw[i]);
+}
+// main, end of phase C: close block 1, run block 2 from the gathered table words, return the digest
+TOYNI_HD Digest coop_main_finish(const ShaRegs& s1, const uint32_t (&kw2)[64]) {
+    Sha256State st = sha256_init();
+    st.h[0] += s1.a; st.h[1] += s1.b; st.h[2] += s1.c; st.h[3] += s1.d; st.h[4] += s1.e; st.h[5] += s1.f; st.h[6] += s1.g; st.h[7] += s1.h;
+    ShaRegs s{st.h[0], st.h[1], st.h[2], st.h[3], st.h[4], st.h[5], st.h[6], st.h[7]};
+#pragma unroll
+    for (int i = 0; i < 64; ++i) sha_round(s, kw2[i]);
+    st.h[0] += s.a; st.h[1] += s.b; st.h[2] += s.c; st.h[3] += s.d; st.h[4] += s.e; st.h[5] += s.f; st.h[6] += s.g; st.h[7] += s.h;
+    return digest_of(st);
+}
+
 }  // namespace toyni
