@@ -52,8 +52,8 @@ typedef struct toyni_ntt_ctx toyni_ntt_ctx;
 
 /* ------------------------------------------------------------------------------------------------
  * 1. The reference's ABI, symbol for symbol (cuda/ntt_kernel.cu:211-318; extern block src/ntt.rs:95-110).
- *    The reference's own extern block binds these nine with TWO edits: the link name
- *    (`ntt_cuda` -> `toyni_hip`) and `cudaGetDeviceCount` (libcudart, src/ntt.rs:102) -> toyni_device_count.
+ *    The reference's own extern block binds all ten of its symbols with ONE edit: the link name
+ *    (`ntt_cuda` -> `toyni_hip`).
  *    `count` is in u64 ELEMENTS.
  * ---------------------------------------------------------------------------------------------- */
 void* ntt_ctx_create(uint32_t n);                       /* cuda/ntt_kernel.cu:213-234; NULL on error */
@@ -66,7 +66,11 @@ int cuda_copy_to_device(uint64_t* d_dest, const uint64_t* h_src, size_t count); 
 int cuda_copy_from_device(uint64_t* h_dest, const uint64_t* d_src, size_t count);  /* :310-312 */
 const char* cuda_get_error_string(int error);           /* :314-316 */
 
-/* Replaces the raw `cudaGetDeviceCount` the reference takes from libcudart (src/ntt.rs:102,147). */
+/* The tenth symbol of the reference's extern block, `cudaGetDeviceCount` (src/ntt.rs:102,147), comes from libcudart there.  It is
+ * exported here under the same name and signature (count of HIP devices, 0 = success), so the reference's extern block links against
+ * this library with ONE edit, the link name (`ntt_cuda` -> `toyni_hip`); toyni_device_count is the same call under a neutral name,
+ * which rust/src/ntt_gpu.rs binds. */
+int cudaGetDeviceCount(int* count);
 int toyni_device_count(int* count);
 const char* toyni_error_string(int status);
 

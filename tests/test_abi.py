@@ -20,8 +20,8 @@ def lib():
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "toyni_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\(", src)
-    return sorted({n for n in names if n.startswith(("toyni_", "ntt_", "intt_", "cuda_"))})
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)
+    return sorted({n for n in names if n.startswith(("toyni_", "ntt_", "intt_", "cuda_", "cudaGet"))})
 
 
 def test_header_symbols_all_exported(lib):
@@ -50,10 +50,15 @@ def test_measurement_hooks_live_in_the_tools_build_only(lib):
 
 
 def test_reference_abi_names_present(lib):
-    # the nine symbols src/ntt.rs:95-110 binds (cudaGetDeviceCount is replaced by toyni_device_count)
+    # all ten symbols src/ntt.rs:95-110 binds, cudaGetDeviceCount (libcudart's in the reference) included: the reference's extern
+    # block links with the link name as its only edit; toyni_device_count is the same call under a neutral name
     for name in ["ntt_ctx_create", "ntt_ctx_destroy", "ntt_run_inplace", "intt_run_inplace", "cuda_malloc", "cuda_free",
-                 "cuda_copy_to_device", "cuda_copy_from_device", "cuda_get_error_string", "toyni_device_count"]:
+                 "cuda_copy_to_device", "cuda_copy_from_device", "cuda_get_error_string", "cudaGetDeviceCount", "toyni_device_count"]:
         assert hasattr(lib.lib, name)
+    import ctypes
+    a, b = ctypes.c_int(-1), ctypes.c_int(-2)
+    ra, rb = lib.lib.cudaGetDeviceCount(ctypes.byref(a)), lib.lib.toyni_device_count(ctypes.byref(b))
+    assert (ra, a.value) == (rb, b.value)
 
 
 def test_error_strings(lib):
@@ -92,9 +97,9 @@ def _c_prototypes():
     src = open(os.path.join(ROOT, "include", "toyni_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
-        if name.startswith(("toyni_", "ntt_", "intt_", "cuda_")):
+        if name.startswith(("toyni_", "ntt_", "intt_", "cuda_", "cudaGet")):
             protos[name] = 0 if args in ("", "void") else args.count(",") + 1
     return protos
 
@@ -103,12 +108,12 @@ def test_rust_and_integration_bindings_match_the_header():
     # No Rust toolchain exists here, so at least keep the shipped extern blocks honest: every function the
     # Rust binding (rust/src/ntt_gpu.rs) and INTEGRATION.md declare must exist in the header with the same arity.
     protos = _c_prototypes()
-    decl = re.compile(r"\bfn\s+([a-z_][a-z0-9_]*)\s*\(([^)]*)\)\s*(?:->\s*[^;{]+)?;")
+    decl = re.compile(r"\bfn\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(([^)]*)\)\s*(?:->\s*[^;{]+)?;")
     checked = 0
     for path in ("rust/src/ntt_gpu.rs", "INTEGRATION.md"):
         text = open(os.path.join(ROOT, path)).read()
         for name, args in decl.findall(text):
-            if not name.startswith(("toyni_", "ntt_", "intt_", "cuda_")):
+            if not name.startswith(("toyni_", "ntt_", "intt_", "cuda_", "cudaGet")):
                 continue
             assert name in protos, f"{path}: {name} is not declared in include/toyni_hip.h"
             arity = 0 if not args.strip() else args.count(",") + 1

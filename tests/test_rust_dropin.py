@@ -72,10 +72,10 @@ def test_following_integration_md_produces_a_linkable_archive(tmp_path):
                           "-Wl,-Bstatic", "-ltoyni_hip", "-Wl,-Bdynamic", "-lamdhip64", "-lstdc++", "-lm", "-lpthread"],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
-    # the reference's nine symbols (src/ntt.rs:95-110, minus cudaGetDeviceCount which toyni_device_count replaces) are in the archive
+    # all ten symbols of the reference's extern block (src/ntt.rs:95-110; cudaGetDeviceCount comes from libcudart there) are in the archive
     syms = subprocess.run(["nm", "--defined-only", str(lib)], capture_output=True, text=True).stdout
     for name in ("ntt_ctx_create", "ntt_ctx_destroy", "ntt_run_inplace", "intt_run_inplace", "cuda_malloc", "cuda_free",
-                 "cuda_copy_to_device", "cuda_copy_from_device", "cuda_get_error_string", "toyni_device_count"):
+                 "cuda_copy_to_device", "cuda_copy_from_device", "cuda_get_error_string", "cudaGetDeviceCount", "toyni_device_count"):
         assert re.search(rf"\bT {name}\b", syms), f"{name} not defined in libtoyni_hip.a"
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "CPP OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]

@@ -59,6 +59,7 @@ SIGNATURES = {
     "cuda_copy_to_device": (c_int, [c_void_p, c_void_p, c_size]),
     "cuda_copy_from_device": (c_int, [c_void_p, c_void_p, c_size]),
     "cuda_get_error_string": (ctypes.c_char_p, [c_int]),
+    "cudaGetDeviceCount": (c_int, [ctypes.POINTER(c_int)]),
     "toyni_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "toyni_error_string": (ctypes.c_char_p, [c_int]),
     # section 2

@@ -608,13 +608,58 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const Digest* __restr
     }
 }
 
+// ---- the node hash on two waves (merkle_kernels.hpp, "a node hash on TWO waves") ----
+__device__ const ShaB2Table SHA_B2 = make_sha_b2_table();   // K + W of a node's second block for each value of its one data byte (64 KiB)
+
+// One node per lane of a MAIN wave, its HELPER wave (the next wave of the workgroup: another SIMD) computing block 1's message
+// schedule.  Both roles, and pairs that have no node at this level (active == false), execute both barriers.  All reads of the
+// children happen before the first barrier.  helper / active are wave-uniform (SGPR conditions: scalar branches, not masks).
+__device__ inline Digest merkle_node_coop(const Digest& l, const Digest& r, uint32_t* sched, uint32_t lane, bool helper, bool active) {
+    uint32_t w[16], last = 0u, kw2[64];
+    ShaRegs st{};
+    if (active) {
+        node_block1(l, r, w, last);
+        if (helper) {
+            coop_helper_schedule<16, 24>(w, sched, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) kw2[i] = SHA_B2.kw[i][last];   // 64 gathers from a 64 KiB table, in flight while block 1 runs
+            coop_main_first16(st, w);
+        }
+    }
+    TOYNI_LDS_BARRIER();
+    if (active) {
+        if (helper) coop_helper_schedule<40, 24>(w, sched, lane);
+        else coop_main_rounds<16>(st, sched, lane);
+    }
+    TOYNI_LDS_BARRIER();
+    Digest d{};
+    if (active && !helper) {
+        coop_main_rounds<40>(st, sched, lane);
+        d = coop_main_finish(st, kw2);
+    }
+    return d;
+}
+
+// A level of up <= 2^15 nodes (the chip cannot be filled: one plain wave per 64 nodes would leave most SIMDs idle anyway): 128-thread
+// workgroups, one main + one helper wave per 64 nodes.  Lanes past the end hash the last node again and store nothing.
+__global__ void __launch_bounds__(128) merkle_level_coop_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, size_t m, size_t up) {
+    __shared__ uint32_t sched[COOP_SCHED_WORDS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool helper = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
+    const size_t i0 = (size_t)blockIdx.x * 64u + lane;
+    const size_t i = i0 < up ? i0 : up - 1;
+    const Digest l = cur[2 * i];
+    const Digest r = (2 * i + 1 < m) ? cur[2 * i + 1] : l;  // odd level: duplicate the last node (src/merkle.rs:38-42)
+    const Digest d = merkle_node_coop(l, r, sched, lane, helper, true);
+    if (!helper && i0 < up) next[i0] = d;
+}
+
 // All remaining levels of a tree whose current level has m <= MERKLE_TAIL digests, in ONE workgroup: the level lives in
 // LDS, each round halves it (odd rounds duplicate the last node) and is also written to global memory (the proofs need
 // every level).  Replaces ~log2(m) tiny launches per tree -- the FRI layers of a proof are mostly trees this small.
-// Round 3: 512 threads, ONE node per thread (round 2: 256 threads, two nodes per thread at the 512-node level).  A 2048-digest tail
-// (1024 threads) was measured and is slower: the 1024-node level then runs four waves per SIMD on one CU where the level kernel
-// spreads it over four CUs (2^11-leaf FRI round 118 against 106 us, profiles/r03_fri_rounds_*.txt).
-constexpr uint32_t MERKLE_TAIL = 1024;
+// Round 3: every level here runs the two-wave node hash: 8 waves = 4 main / helper pairs, up to 256 nodes per level.
+constexpr uint32_t MERKLE_TAIL = 512;
 constexpr uint32_t MERKLE_TAIL_T = 512;
 // `notify` (optional): 9 words of pinned host memory -- the root, then a sequence number stored with system-scope release once
 // the root is there.  The host polls that word instead of paying a copy and a stream synchronisation for 32 bytes.
@@ -627,34 +672,36 @@ __device__ inline void merkle_notify(const Digest& root, uint32_t* notify, uint3
 __global__ void merkle_notify_kernel(const Digest* __restrict__ root, uint32_t* notify, uint32_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) merkle_notify(*root, notify, seq);
 }
-// the levels above `lvl[0 .. m)` (already in LDS and in global memory), one workgroup; m <= MERKLE_TAIL, so a level above has at
-// most MERKLE_TAIL / 2 = blockDim nodes: one per thread, and the chain of dependent hashes is as short as the tree is deep
-__device__ inline void merkle_tail_levels(Digest* lvl, Digest* __restrict__ next, uint32_t m, uint32_t* notify, uint32_t seq) {
+__global__ void __launch_bounds__(MERKLE_TAIL_T) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m,
+                                                                    uint32_t* notify, uint32_t seq) {
+    __shared__ Digest lvl[MERKLE_TAIL];
+    __shared__ uint32_t sched[MERKLE_TAIL_T / 128][COOP_SCHED_WORDS];
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pair = wave >> 1;
+    const bool helper = (wave & 1u) != 0u;
     while (m > 1) {
-        const uint32_t up = (m + 1) / 2, i = threadIdx.x;
-        Digest mine;
-        if (i < up) {
-            const Digest l = lvl[2 * i];
-            const Digest r = (2 * i + 1 < m) ? lvl[2 * i + 1] : l;
-            mine = merkle_node(l, r);
+        const uint32_t up = (m + 1) / 2;
+        const bool active = pair * 64u < up;               // wave-uniform
+        const uint32_t i0 = pair * 64u + lane;
+        const uint32_t i = i0 < up ? i0 : up - 1;
+        Digest l{}, r{};
+        if (active) {
+            l = lvl[2 * i];
+            r = (2 * i + 1 < m) ? lvl[2 * i + 1] : l;
         }
-        __syncthreads();  // every read of the old level is done
-        if (i < up) {
-            lvl[i] = mine;
-            next[i] = mine;
+        const Digest d = merkle_node_coop(l, r, sched[pair], lane, helper, active);   // its first barrier: every read of the old level is done
+        if (active && !helper && i0 < up) {
+            lvl[i0] = d;
+            next[i0] = d;
         }
-        __syncthreads();
+        TOYNI_LDS_BARRIER();
         next += up;
         m = up;
     }
     if (notify && threadIdx.x == 0) merkle_notify(lvl[0], notify, seq);
-}
-__global__ void __launch_bounds__(MERKLE_TAIL_T) merkle_tail_kernel(const Digest* __restrict__ cur, Digest* __restrict__ next, uint32_t m,
-                                                                    uint32_t* notify, uint32_t seq) {
-    __shared__ Digest lvl[MERKLE_TAIL];
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) lvl[i] = cur[i];
-    __syncthreads();
-    merkle_tail_levels(lvl, next, m, notify, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1184,6 +1231,9 @@ int toyni_device_count(int* count) {
     if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); }
     return (int)e;
 }
+
+// the reference's extern block takes this name from libcudart (src/ntt.rs:102): same signature, same meaning, HIP devices
+int cudaGetDeviceCount(int* count) { return toyni_device_count(count); }
 
 int toyni_set_device(int device) { return (int)hipSetDevice(device); }
 
@@ -1930,9 +1980,15 @@ int toyni_merkle_commit_device(const uint32_t* d_values, const uint8_t* d_salts,
 static int enqueue_merkle_upper(uint8_t* d_levels, size_t n, hipStream_t s, uint32_t* notify, uint32_t seq) {
     Digest* cur = reinterpret_cast<Digest*>(d_levels);
     size_t m = n;
+    // levels the chip cannot fill take the two-wave node hash (TOYNI_MERKLE_COOP_LOG = largest log2(nodes) that does; default 14,
+    // -1 = never: A/B runs)
+    static const int coop_log = [] { const char* e = std::getenv("TOYNI_MERKLE_COOP_LOG"); return e ? std::atoi(e) : 14; }();
     while (m > MERKLE_TAIL) {
         const size_t up = (m + 1) / 2;
-        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid_for(up)), dim3(256), 0, s, (const Digest*)cur, cur + m, m, up);
+        if (coop_log >= 0 && up <= ((size_t)1 << coop_log))
+            hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((unsigned)((up + 63) / 64)), dim3(128), 0, s, (const Digest*)cur, cur + m, m, up);
+        else
+            hipLaunchKernelGGL(merkle_level_kernel, dim3(grid_for(up)), dim3(256), 0, s, (const Digest*)cur, cur + m, m, up);
         cur += m;
         m = up;
     }
