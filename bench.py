@@ -536,21 +536,23 @@ def main():
     # rank 0 checks that N ranks sat on N different GPUs (under RCCL; the gloo rehearsal shares devices on purpose) and prints the
     # per-rank step times next to the maximum that `value` is computed from.
     prop = torch.cuda.get_device_properties(dev)
+    import zlib
+    uuid_tag = zlib.crc32(str(getattr(prop, "uuid", "")).encode())      # a second identity next to the PCI id (either one distinct = distinct GPUs)
     mine = torch.tensor([rank, dev.index, getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
-                         batch, int(wall * 1e9)], dtype=torch.int64, device=coll_dev)
+                         batch, int(wall * 1e9), uuid_tag], dtype=torch.int64, device=coll_dev)
     table = [torch.zeros_like(mine) for _ in range(world)]
     if distributed:
         dist.all_gather(table, mine)
     else:
         table = [mine]
     ranks_table = [{"rank": int(t[0]), "device": int(t[1]), "pci": "%04x:%02x:%02x" % (int(t[2]), int(t[3]) & 0xFF, int(t[4]) & 0xFF),
-                    "transforms_per_step": 2 * int(t[5]), "ms_per_step": int(t[6]) / 1e6 / args.steps} for t in table]
+                    "uuid_crc32": "%08x" % int(t[7]), "transforms_per_step": 2 * int(t[5]), "ms_per_step": int(t[6]) / 1e6 / args.steps} for t in table]
     if rank == 0 and distributed:
         print("rank  device  pci           transforms/step  ms/step", file=sys.stderr)
         for r in ranks_table:
             print("%4d  %6d  %-12s  %15d  %.3f" % (r["rank"], r["device"], r["pci"], r["transforms_per_step"], r["ms_per_step"]), file=sys.stderr)
         if backend == "nccl":
-            assert len({r["pci"] for r in ranks_table}) == world, f"{world} ranks share GPUs: {ranks_table}"
+            assert len({(r["pci"], r["uuid_crc32"]) for r in ranks_table}) == world, f"{world} ranks share GPUs: {ranks_table}"
     total_batch = sum(r["transforms_per_step"] for r in ranks_table) // 2
     transforms = 2 * total_batch * args.steps
     value = transforms * n / wall_max

@@ -317,6 +317,8 @@ int toyni_widen_u32_to_u64(const uint32_t* d_in, uint64_t* d_out, size_t count, 
  * to HIP's legacy default stream.  toyni_stream_destroy waits for the stream's work first. */
 int toyni_stream_create(void** stream, int device);
 int toyni_stream_destroy(void* stream);
+/* Ordering between two streams: what is enqueued on `stream` after this call runs after everything enqueued on `after` so far. */
+int toyni_stream_wait(void* stream, void* after);
 int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); with a context: also releases what that stream outgrew */
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);

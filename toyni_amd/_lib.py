@@ -125,6 +125,7 @@ SIGNATURES = {
     "toyni_widen_u32_to_u64": (c_int, [c_void_p, c_void_p, c_size, c_void_p]),
     "toyni_stream_create": (c_int, [ctypes.POINTER(c_void_p), c_int]),
     "toyni_stream_destroy": (c_int, [c_void_p]),
+    "toyni_stream_wait": (c_int, [c_void_p, c_void_p]),
     "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
     "toyni_ntt_ctx_trim": (c_int, [c_void_p]),
     "toyni_set_device": (c_int, [c_int]),

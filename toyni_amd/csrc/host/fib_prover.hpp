@@ -153,6 +153,7 @@ class Prover {
         TOYNI_FIB_TRY(toyni_ntt_ctx_create((uint32_t)n_, device_, &ctx_n_), "trace-domain context");
         TOYNI_FIB_TRY(toyni_ntt_ctx_create((uint32_t)N_, device_, &ctx_N_), "LDE-domain context");
         TOYNI_FIB_TRY(toyni_stream_create(&stream_, toyni_ntt_ctx_device(ctx_N_)), "stream");
+        TOYNI_FIB_TRY(toyni_stream_create(&side_, toyni_ntt_ctx_device(ctx_N_)), "stream");
         const size_t tree_bytes = toyni_merkle_total_digests(N_) * 32;
         salt_bytes_ = ((3 * N_ + salted_fri_) * 16 + 63) & ~(size_t)63;
         struct { void** p; size_t bytes; } bufs[] = {
@@ -232,7 +233,11 @@ class Prover {
         }
         const size_t ncoef_t = n_ + MASK_DEGREE;       // trace_poly = compact[0 .. ncoef_t)
         TOYNI_FIB_TRY(toyni_lde_device(ctx_N_, d_compact_, d_trace_lde_, 1, log_N_ - log_c_, COSET_SHIFT, s), "LDE");
-        TOYNI_FIB_TRY(toyni_merkle_commit_device(d_trace_lde_, salts_trace, N_, d_trace_tree_, s), "trace commitment");
+        // The trace tree is not needed before z is drawn (its root is absorbed together with the quotient tree's): it is built on a side
+        // stream while the constraint / quotient kernels, the two INTTs and the quotient tree run on the main one.  A tree's upper ~14
+        // levels are a chain of dependent hashes that keeps a handful of CUs busy; two trees side by side hide each other's chains.
+        TOYNI_FIB_TRY(toyni_stream_wait(side_, s), "stream order");
+        TOYNI_FIB_TRY(toyni_merkle_commit_device(d_trace_lde_, salts_trace, N_, d_trace_tree_, times ? s : side_), "trace commitment");
         if (times) lap(times->interpolate_lde_commit);
 
         // ---- 2. constraint & quotient (:133-153) and the reference's two ifft calls ----
@@ -240,6 +245,7 @@ class Prover {
         TOYNI_FIB_TRY(toyni_coset_ntt_device(ctx_N_, d_c_, d_c_, 1, COSET_SHIFT, 1, s), "ifft (c_poly)");          // :145
         TOYNI_FIB_TRY(toyni_coset_ntt_device(ctx_N_, d_q_, d_qpoly_, 1, COSET_SHIFT, 1, s), "ifft (q_poly)");      // :151
         TOYNI_FIB_TRY(toyni_merkle_commit_device(d_q_, salts_quot, N_, d_quot_tree_, s), "quotient commitment");
+        TOYNI_FIB_TRY(toyni_stream_wait(s, side_), "stream order");          // both trees are complete before their roots are read
         const size_t root_off = (toyni_merkle_total_digests(N_) - 1) * 32;
         uint8_t* roots = reinterpret_cast<uint8_t*>(stage + stage_words);
         TOYNI_FIB_TRY(down(roots, d_trace_tree_ + root_off, 32), "root down");
@@ -393,6 +399,7 @@ class Prover {
             if (p) (void)toyni_free(p);
         if (h_pinned_) (void)toyni_host_free(h_pinned_);
         if (stream_) (void)toyni_stream_destroy(stream_);
+        if (side_) (void)toyni_stream_destroy(side_);
         if (ctx_n_) (void)toyni_ntt_ctx_destroy(ctx_n_);
         if (ctx_N_) (void)toyni_ntt_ctx_destroy(ctx_N_);
     }
@@ -404,7 +411,7 @@ class Prover {
     Traffic traffic_;
     std::vector<size_t> sizes_;       // folded layer sizes N/2 ... final_size
     toyni_ntt_ctx *ctx_n_ = nullptr, *ctx_N_ = nullptr;
-    void* stream_ = nullptr;
+    void *stream_ = nullptr, *side_ = nullptr;
     uint32_t *d_compact_ = nullptr, *d_trace_lde_ = nullptr, *d_c_ = nullptr, *d_q_ = nullptr, *d_qpoly_ = nullptr, *d_deep_ = nullptr, *d_layers_ = nullptr,
              *d_ood_ = nullptr, *d_idx_ = nullptr;
     uint8_t *d_trace_tree_ = nullptr, *d_quot_tree_ = nullptr, *d_deep_tree_ = nullptr, *d_fri_trees_ = nullptr, *d_salts_ = nullptr, *d_records_ = nullptr;

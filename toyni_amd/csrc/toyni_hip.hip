@@ -2304,6 +2304,18 @@ int toyni_stream_destroy(void* stream) {
     return (int)hipStreamDestroy((hipStream_t)stream);
 }
 
+// Cross-stream ordering without exposing events: everything enqueued on `stream` after this call waits for everything enqueued on
+// `after` before it.  (An event is created, recorded on `after`, waited for on `stream` and released; the wait stays enqueued.)
+int toyni_stream_wait(void* stream, void* after) {
+    if (stream == after) return TOYNI_OK;
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)after);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+    (void)hipEventDestroy(ev);   // released once the recorded work has completed; the enqueued wait keeps its own reference
+    return (int)e;
+}
+
 int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (c) {
