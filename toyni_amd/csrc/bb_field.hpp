@@ -35,14 +35,6 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TOYNI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define TOYNI_PIN(v) asm volatile("" : "+v"(v))
-// the same for the links of a running twiddle product: opaque (the chain is not re-associated into many live powers) but NOT volatile,
-// so the scheduler may still move independent instructions across it -- a volatile asm between a v_mad_u64_u32 and the next one
-// that reads its high half leaves the hazard wait state to an s_nop (61 per tile in the 1024-point column pass)
-#if defined(TOYNI_PIN_CHAIN_VOLATILE)
-#define TOYNI_PIN_CHAIN(v) asm volatile("" : "+v"(v))
-#else
-#define TOYNI_PIN_CHAIN(v) asm("" : "+v"(v))
-#endif
 // s_waitcnt vmcnt(0) alone (expcnt / lgkmcnt fields at their maxima), as a builtin so that the compiler's own
 // wait-count insertion knows every earlier VMEM operation has retired
 #define TOYNI_WAIT_VMEM0() __builtin_amdgcn_s_waitcnt(0x0F70)
@@ -57,7 +49,6 @@
 #else
 #define TOYNI_SCHED_FENCE() ((void)0)
 #define TOYNI_PIN(v) ((void)0)
-#define TOYNI_PIN_CHAIN(v) ((void)0)
 #define TOYNI_WAIT_VMEM0() ((void)0)
 #define TOYNI_WAIT_VMEM_ALLOW(N) ((void)0)
 #define TOYNI_BARRIER() ((void)0)

@@ -335,27 +335,18 @@ struct Pass {
 #define TOYNI_STORE(B, V) st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)(B) * step), off0, (V))
 #endif
         if (KIND == KIND_COL) {
-            // the running product is advanced BEFORE the current factor is applied: the application's first v_mad_u64_u32 then reads a
-            // value produced six instructions earlier, not the high half of the v_mad_u64_u32 just before it -- that back-to-back
-            // dependence costs a wait state (an s_nop per element in the round-2 order: 61 per tile of the 1024-point column pass)
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                uint32_t nxt = tw;
-                if (b + 1 < NB) { nxt = mont_mul_lazy(tw, twd.g); TOYNI_PIN_CHAIN(nxt); }
-                TOYNI_SCHED_FENCE();   // or the scheduler moves this element's application above the advance and the next one lands behind it
                 TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
-                tw = nxt;
+                if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else if (a.cs_mode == 2u) {  // inverse coset transform: * s^k, k = k0 + b * (register step), running product
             uint32_t tw = twd.a0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                uint32_t nxt = tw;
-                if (b + 1 < NB) { nxt = mont_mul_lazy(tw, twd.g); TOYNI_PIN_CHAIN(nxt); }
-                TOYNI_SCHED_FENCE();
                 TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
-                tw = nxt;
+                if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
         } else {
             const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
@@ -667,12 +658,9 @@ struct Pass {
         if (KIND != KIND_ROW_T && a.cs_mode == 1u) {
             uint32_t tw = mont_mul(r.hi, r.lo);
 #pragma unroll
-            for (uint32_t i = 0; i < NZ; ++i) {   // the product is advanced before it is applied (see finish(): no back-to-back dependent mads)
-                uint32_t nxt = tw;
-                if (i + 1 < NZ) { nxt = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN_CHAIN(nxt); }
-                TOYNI_SCHED_FENCE();
+            for (uint32_t i = 0; i < NZ; ++i) {
                 x[i] = mont_mul(x[i], tw);
-                tw = nxt;
+                if (i + 1 < NZ) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
             }
         }
     }
