@@ -339,6 +339,20 @@ def profile_provenance(path):
     without .git: there profiles/PROVENANCE.json, written by tools/stamp_profiles.py at commit time, answers instead)."""
     import subprocess
     rel = os.path.relpath(path, ROOT)
+    # 1. exact: the profile carries the sha256 of the sources it measured (tools/csrc_hash.py, recorded on the box at collection time)
+    measured = None
+    try:
+        if path.endswith(".json"):
+            measured = json.load(open(path)).get("csrc_sha256")
+        elif os.path.exists(path.replace(".csv", ".meta.json")):
+            measured = json.load(open(path.replace(".csv", ".meta.json"))).get("csrc_sha256")
+    except (OSError, ValueError):
+        measured = None
+    if measured:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_hash import csrc_sha256
+        return "sources sha256 " + measured[:12], measured != csrc_sha256()
+    # 2. fallback for older profiles: git history, or profiles/PROVENANCE.json where there is no .git
     try:
         h = subprocess.run(["git", "log", "-1", "--format=%h", "--", rel], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
         if h:
@@ -363,7 +377,7 @@ def stamp(src, path):
     if stale:
         print(f"bench.py: WARNING: {os.path.relpath(path, ROOT)} was measured at commit {h}; toyni_amd/csrc has changed since -- "
               f"re-collect it (tools/collect_profiles.sh) before quoting roofline.traffic", file=sys.stderr)
-    return f"{src} [measured at commit {h}{'; csrc changed since: STALE' if stale else ''}]"
+    return f"{src} [measured at {h if h.startswith('sources') else 'commit ' + h}{'; kernels changed since: STALE' if stale else '; identical to the running sources'}]"
 
 
 def committed_fold_profile():

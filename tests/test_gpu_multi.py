@@ -436,3 +436,39 @@ def test_device_calls_can_be_captured_into_a_graph(ta):
                 assert (got[b] == oracle.ntt(x.reshape(batch, n)[b])).all(), (log_n, rep, b)
         del g
         ctx.destroy()
+
+
+def test_stream_plumbing_for_hosts_without_a_hip_binding(ta):
+    """include/toyni_hip.h section 4 (round 3): streams, stream-ordered copies / fills and cross-stream ordering as a Rust caller would
+    use them between the library's calls -- here the shape of the C++ prover's first steps: fill, upload, transform on stream A,
+    consume on stream B after toyni_stream_wait, download."""
+    lib = ta._lib.lib
+    n = 1 << 16
+    x = oracle.splitmix(n, 7700).astype(np.uint32)
+    sa, sb = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.toyni_stream_create(ctypes.byref(sa), -1) == 0 and lib.toyni_stream_create(ctypes.byref(sb), -1) == 0
+    d, e = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.toyni_malloc(ctypes.byref(d), 8 * n) == 0 and lib.toyni_malloc(ctypes.byref(e), 4 * n) == 0
+    pin = ta.PinnedArray(n)                                    # u64 elements of pinned host memory: used as 2 n u32 words
+    host = pin.array.view(np.uint32)
+    host[:n] = x
+    ctx = ta.NttContext(n)
+    assert lib.toyni_memset_async(d, 0, 8 * n, sa) == 0        # second half stays zero
+    assert lib.toyni_memcpy_h2d_async(d, host.ctypes.data, 4 * n, sa) == 0
+    ctx.run_device(d.value, d.value, 1, False, stream=sa.value)
+    assert lib.toyni_stream_wait(sb, sa) == 0                  # B's work starts after A's transform
+    assert lib.toyni_memcpy_d2d_async(e, d, 4 * n, sb) == 0
+    ctx.run_device(e.value, e.value, 1, True, stream=sb.value)
+    assert lib.toyni_memcpy_d2h_async(host.ctypes.data + 4 * n, e, 4 * n, sb) == 0
+    assert lib.toyni_stream_synchronize(None, sb) == 0
+    assert (host[n:2 * n] == x).all()                          # forward on A, inverse on B: the round trip crossed the streams in order
+    out = np.empty(2 * n, dtype=np.uint32)
+    assert lib.toyni_stream_synchronize(None, sa) == 0
+    assert lib.toyni_memcpy_d2h(out.ctypes.data, d, 8 * n) == 0
+    assert (out[:n] == oracle.ntt(x.astype(np.uint64))).all() and (out[n:] == 0).all()
+    assert lib.toyni_stream_wait(sa, sa) == 0                  # a stream waiting for itself is a no-op
+    ctx.destroy()
+    pin.free()
+    for p in (d, e):
+        assert lib.toyni_free(p) == 0
+    assert lib.toyni_stream_destroy(sa) == 0 and lib.toyni_stream_destroy(sb) == 0 and lib.toyni_stream_destroy(None) == 0

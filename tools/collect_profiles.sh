@@ -12,6 +12,7 @@ SUFFIX=""
 [ "$LOGN" != "20" ] && SUFFIX="_2p$LOGN"
 OUT=gpurun_out/profiles_$TAG$SUFFIX
 mkdir -p $OUT
+python3 tools/csrc_hash.py > $OUT/csrc_sha256.txt   # which kernels these profiles measure (bench.py checks it)
 CMD="python3 bench.py --steps 3 --warmup 1 --log-n $LOGN --batch $BATCH --no-extras --no-cpu-baseline"
 # the timing pass runs bench.py's DEFAULT step counts (the command the bench line is judged on): averages over 20 steps, not over a
 # handful of launches that are still warming up; the counter passes replay kernels and keep the short run

@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r02}
 OUT=gpurun_out/profiles_${TAG}_side
 mkdir -p $OUT
+python3 tools/csrc_hash.py > $OUT/csrc_sha256.txt   # which kernels these profiles measure (bench.py checks it)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fold_stats -- python3 tools/foldbench.py > $OUT/fold_stats.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fold_fetch -- python3 tools/foldbench.py > $OUT/fold_fetch.log 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/fold_write -- python3 tools/foldbench.py > $OUT/fold_write.log 2>&1 || exit 1

@@ -60,6 +60,10 @@ for k, v in allc.items():
             "rocprof_avg_ns": durations.get(k),
         }
 json.dump(traffic, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1, sort_keys=True)
+hf = f"{src}/csrc_sha256.txt"
+if os.path.exists(hf):
+    traffic["csrc_sha256"] = open(hf).read().strip()
+    json.dump(traffic, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1, sort_keys=True)
 bj = f"{src}/bench_under_rocprof.json"
 if os.path.exists(bj) and os.path.getsize(bj):
     shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof{suffix}.json")

@@ -49,6 +49,8 @@ with open(f"profiles/{tag}_fold_stats.csv", "w", newline="") as out:
         f_, w_ = fetch.get(r["Name"]), write.get(r["Name"])
         w.writerow([r["Name"], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], f_[0] if f_ else "", w_[0] if w_ else "",
                     f_[2] if f_ else "", w_[2] if w_ else "", (2 * f_[2] + w_[2]) * 1024 if f_ and w_ else ""])
+if os.path.exists(f"{src}/csrc_sha256.txt"):
+    json.dump({"csrc_sha256": open(f"{src}/csrc_sha256.txt").read().strip()}, open(f"profiles/{tag}_fold_stats.meta.json", "w"))
 lat = stats_rows("latency_stats", lambda name: "ntt_pass" in name)
 with open(f"profiles/{tag}_latency_stats.csv", "w", newline="") as out:
     w = csv.writer(out)
