@@ -906,7 +906,7 @@ def main():
             assert cj.get("gpu") and "error" not in cj, line[:300]
             ms_sorted = sorted(cj["ms"])
             fib = {"ms": ms_sorted[len(ms_sorted) // 2], "ms_all": cj["ms"], "phase_ms_with_syncs": cj["phases"], "pcie_per_proof": cj["pcie"],
-                   "proof_bytes": cj["proof_bytes"], "caller": "C++ (toyni_amd/csrc/host/fib_prover.hpp via build/fib_prove), one process, one stream",
+                   "proof_bytes": cj["proof_bytes"], "caller": "C++ (toyni_amd/csrc/host/fib_prover.hpp via build/fib_prove), one process, two streams (the trace tree is built beside the quotient kernels)",
                    "note": "wall time per proof, warm, median of 9, salts and mask from a ChaCha20 keystream on the device; the reference prover is "
                            "infeasible at this size (O(n^3) interpolation, SURVEY F5)"}
         except Exception as exc:

@@ -286,6 +286,18 @@ int toyni_poly_eval_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, size_t 
 size_t toyni_merkle_open_record_bytes(size_t n);
 int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* d_values, const uint8_t* d_salts, const uint32_t* d_indices,
                              size_t nidx, uint8_t* d_out, void* stream);
+/* The same for several trees at once (the query phase of a proof opens the trace, quotient and DEEP trees and every FRI layer's:
+ * src/fibonacci.rs:249-295): one launch per 32 trees instead of one per tree.  Every field as in toyni_merkle_open_device. */
+typedef struct {
+    const uint8_t* d_levels;
+    size_t n;
+    const uint32_t* d_values;
+    const uint8_t* d_salts;
+    const uint32_t* d_indices;
+    size_t nidx;
+    uint8_t* d_out;
+} toyni_merkle_open_group;
+int toyni_merkle_open_groups_device(const toyni_merkle_open_group* groups, size_t ngroups, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 4. Plumbing

@@ -102,6 +102,47 @@ def test_merkle_openings(env, n, salted):
         assert o["salt"] == (salts[o["index"]].tobytes() if salted else b"")
 
 
+def test_merkle_openings_of_several_trees_in_one_launch(env):
+    """toyni_merkle_open_groups_device (round 3): the query phase opens ~19 trees per proof; one launch for all of them must write
+    exactly the records that one toyni_merkle_open_device call per tree writes -- 40 trees here (two launches of <= 32), sizes 1 ...
+    2^12, salted and not, an empty group in the middle."""
+    import ctypes
+    ta, torch, dev = env
+    lib = ta._lib.lib
+
+    class Group(ctypes.Structure):
+        _fields_ = [("d_levels", ctypes.c_void_p), ("n", ctypes.c_size_t), ("d_values", ctypes.c_void_p), ("d_salts", ctypes.c_void_p),
+                    ("d_indices", ctypes.c_void_p), ("nidx", ctypes.c_size_t), ("d_out", ctypes.c_void_p)]
+
+    rng = np.random.default_rng(33)
+    keep, groups, want = [], [], []
+    for k in range(40):
+        n = int(rng.integers(1, 1 << 12)) if k % 7 else 1 << (k % 13)
+        salted = bool(k % 3)
+        vals = oracle.splitmix(n, 900 + k)
+        v = _dev(torch, dev, vals)
+        s = torch.from_numpy(rng.integers(0, 256, (n, 16), dtype=np.uint8)).to(dev) if salted else None
+        lv = torch.empty((lib.toyni_merkle_total_digests(n), 32), dtype=torch.uint8, device=dev)
+        ta.merkle_commit_device(v.data_ptr(), s.data_ptr() if salted else 0, n, lv.data_ptr())
+        nidx = 0 if k == 17 else int(rng.integers(1, 9))
+        it = torch.from_numpy(rng.integers(0, n, max(nidx, 1)).astype(np.int32)).to(dev)
+        rec = ta.prover.merkle_open_record_bytes(n)
+        one = torch.zeros(max(nidx, 1) * rec, dtype=torch.uint8, device=dev)
+        if nidx:
+            ta.prover.merkle_open_device(lv.data_ptr(), n, v.data_ptr(), s.data_ptr() if salted else 0, it.data_ptr(), nidx, one.data_ptr())
+        out = torch.full((max(nidx, 1) * rec,), 0, dtype=torch.uint8, device=dev)
+        keep += [v, s, lv, it, out]
+        want.append((one, out, nidx * rec))
+        groups.append(Group(lv.data_ptr(), n, v.data_ptr(), s.data_ptr() if salted else None, it.data_ptr(), nidx, out.data_ptr()))
+    arr = (Group * len(groups))(*groups)
+    assert lib.toyni_merkle_open_groups_device(arr, len(groups), None) == 0
+    torch.cuda.synchronize()
+    for k, (one, out, nbytes) in enumerate(want):
+        assert torch.equal(one[:nbytes], out[:nbytes]), f"group {k}"
+    arr[3].d_out = None
+    assert lib.toyni_merkle_open_groups_device(arr, len(groups), None) == 10002          # a null pointer in any group: nothing is launched
+
+
 @pytest.mark.parametrize("log_m,salted", [(1, False), (2, True), (5, True), (11, True), (12, False), (16, True), (21, True)])
 def test_fold_commit_round(env, log_m, salted):
     """One protocol round (src/fibonacci.rs:222-245): layer values as fri_fold, tree as build_merkle_tree of the folded layer."""

@@ -109,6 +109,7 @@ SIGNATURES = {
     "toyni_poly_eval_device": (c_int, [c_void_p, c_void_p, c_size, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
     "toyni_merkle_open_record_bytes": (c_size, [c_size]),
     "toyni_merkle_open_device": (c_int, [c_void_p, c_size, c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_void_p]),
+    "toyni_merkle_open_groups_device": (c_int, [c_void_p, c_size, c_void_p]),
     # section 4
     "toyni_malloc": (c_int, [ctypes.POINTER(c_void_p), c_size]),
     "toyni_free": (c_int, [c_void_p]),

@@ -345,6 +345,7 @@ class Prover {
         }
         TOYNI_FIB_TRY(up(d_idx_, hp, 4 * nidx), "query positions up");
         {
+            std::vector<toyni_merkle_open_group> og;
             size_t io = 0, bo = 0, lo = 0, dlo = 0, slo = 0;
             for (size_t k = 0; k < proof.opening_groups.size(); ++k) {
                 auto& gr = proof.opening_groups[k];
@@ -358,10 +359,11 @@ class Prover {
                     levels = d_fri_trees_ + dlo * 32; values = d_layers_ + lo; salts = salts_fri + slo * 16;
                     lo += h; dlo += toyni_merkle_total_digests(h); slo += h;
                 }
-                TOYNI_FIB_TRY(toyni_merkle_open_device(levels, gr.tree_leaves, values, salts, d_idx_ + io, gr.indices.size(), d_records_ + bo, s), "openings");
+                og.push_back(toyni_merkle_open_group{levels, gr.tree_leaves, values, salts, d_idx_ + io, gr.indices.size(), d_records_ + bo});
                 io += gr.indices.size();
                 bo += gr.indices.size() * toyni_merkle_open_record_bytes(gr.tree_leaves);
             }
+            TOYNI_FIB_TRY(toyni_merkle_open_groups_device(og.data(), og.size(), s), "openings");   // every tree's openings: one launch
         }
         proof.opening_records.resize(nbytes);
         TOYNI_FIB_TRY(down(h_pinned_, d_records_, nbytes), "opening records down");

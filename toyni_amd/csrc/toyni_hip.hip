@@ -463,31 +463,46 @@ __global__ void __launch_bounds__(256) poly_eval_final_kernel(const PolyEvalArgs
 }
 
 // Merkle openings: one thread per (opening, level) copies the sibling digest; one thread per opening adds salt, value, flags
-__global__ void __launch_bounds__(256) merkle_open_kernel(const Digest* __restrict__ levels, uint64_t n, const uint32_t* __restrict__ values,
-                                                          const uint4* __restrict__ salts, const uint32_t* __restrict__ indices, uint32_t nidx,
-                                                          uint8_t* __restrict__ out) {
-    const uint32_t depth = merkle_depth(n);
-    const uint64_t rec = merkle_open_record_bytes(n);
-    const uint64_t total = (uint64_t)nidx * (depth + 1);
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+struct OpenGroup {
+    const Digest* levels;
+    uint64_t n;
+    const uint32_t* values;
+    const uint4* salts;
+    const uint32_t* indices;
+    uint32_t nidx;
+    uint8_t* out;
+};
+__device__ __forceinline__ void merkle_open_group(const OpenGroup& g, uint64_t first, uint64_t stride) {
+    const uint32_t depth = merkle_depth(g.n);
+    const uint64_t rec = merkle_open_record_bytes(g.n);
+    const uint64_t total = (uint64_t)g.nidx * (depth + 1);
+    for (uint64_t w = first; w < total; w += stride) {
         const uint32_t k = (uint32_t)(w / (depth + 1)), level = (uint32_t)(w % (depth + 1));
-        const uint64_t index = indices[k];
-        uint8_t* r = out + (uint64_t)k * rec;
+        const uint64_t index = g.indices[k];
+        uint8_t* r = g.out + (uint64_t)k * rec;
         if (level < depth) {
             bool is_left;
-            const uint64_t row = merkle_sibling_row(n, index, level, is_left);
-            reinterpret_cast<Digest*>(r)[level] = levels[row];       // records are 8-byte aligned, digests are u32 words
+            const uint64_t row = merkle_sibling_row(g.n, index, level, is_left);
+            reinterpret_cast<Digest*>(r)[level] = g.levels[row];       // records are 8-byte aligned, digests are u32 words
             r[(uint64_t)depth * 32u + 24u + level] = is_left ? 1 : 0;
         } else {
             uint32_t* tail = reinterpret_cast<uint32_t*>(r + (uint64_t)depth * 32u);
             uint4 sv = make_uint4(0u, 0u, 0u, 0u);
-            if (salts) sv = salts[index];
+            if (g.salts) sv = g.salts[index];
             tail[0] = sv.x; tail[1] = sv.y; tail[2] = sv.z; tail[3] = sv.w;
-            tail[4] = values[index];
+            tail[4] = g.values[index];
             tail[5] = 0u;
         }
     }
+}
+__global__ void __launch_bounds__(256) merkle_open_kernel(const OpenGroup g) {
+    merkle_open_group(g, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+// every tree of a proof in ONE launch (blockIdx.y = tree): the 19 launches of a 2^16-row proof's query phase were ~5 us each
+constexpr uint32_t OPEN_GROUPS_MAX = 32;
+struct OpenGroups { OpenGroup g[OPEN_GROUPS_MAX]; };
+__global__ void __launch_bounds__(256) merkle_open_groups_kernel(const OpenGroups gs) {
+    merkle_open_group(gs.g[blockIdx.y], (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // FRI fold, explicit points: 4 inversions share one Fermat exponentiation (Montgomery's trick)
@@ -2225,9 +2240,37 @@ int toyni_merkle_open_device(const uint8_t* d_levels, size_t n, const uint32_t* 
     if (n == 0 || nidx == 0) return TOYNI_OK;
     if (n > 0xFFFFFFFFull || nidx > 0xFFFFFFFFull || ((uintptr_t)d_levels & 15) || ((uintptr_t)d_salts & 15) || ((uintptr_t)d_out & 7)) return TOYNI_E_RANGE;
     const uint64_t work = (uint64_t)nidx * (merkle_depth(n) + 1);
-    hipLaunchKernelGGL(merkle_open_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const Digest*>(d_levels),
-                       (uint64_t)n, d_values, reinterpret_cast<const uint4*>(d_salts), d_indices, (uint32_t)nidx, d_out);
+    const OpenGroup g{reinterpret_cast<const Digest*>(d_levels), (uint64_t)n, d_values, reinterpret_cast<const uint4*>(d_salts), d_indices, (uint32_t)nidx, d_out};
+    hipLaunchKernelGGL(merkle_open_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, g);
     return (int)hipGetLastError();
+}
+
+// The openings of several trees (a proof's query phase: trace, quotient, DEEP and every FRI layer) gathered by one launch per 32 trees.
+int toyni_merkle_open_groups_device(const toyni_merkle_open_group* groups, size_t ngroups, void* stream) {
+    if (!groups && ngroups) return TOYNI_E_NULL;
+    for (size_t k = 0; k < ngroups; ++k) {
+        const toyni_merkle_open_group& q = groups[k];
+        if (q.n == 0 || q.nidx == 0) continue;
+        if (!q.d_levels || !q.d_values || !q.d_indices || !q.d_out) return TOYNI_E_NULL;
+        if (q.n > 0xFFFFFFFFull || q.nidx > 0xFFFFFFFFull || ((uintptr_t)q.d_levels & 15) || ((uintptr_t)q.d_salts & 15) || ((uintptr_t)q.d_out & 7)) return TOYNI_E_RANGE;
+    }
+    for (size_t k0 = 0; k0 < ngroups; k0 += OPEN_GROUPS_MAX) {
+        OpenGroups gs{};
+        uint32_t cnt = 0;
+        uint64_t most = 0;
+        for (size_t k = k0; k < ngroups && k < k0 + OPEN_GROUPS_MAX; ++k) {
+            const toyni_merkle_open_group& q = groups[k];
+            if (q.n == 0 || q.nidx == 0) continue;
+            gs.g[cnt++] = OpenGroup{reinterpret_cast<const Digest*>(q.d_levels), (uint64_t)q.n, q.d_values, reinterpret_cast<const uint4*>(q.d_salts), q.d_indices,
+                                    (uint32_t)q.nidx, q.d_out};
+            const uint64_t work = (uint64_t)q.nidx * (merkle_depth(q.n) + 1);
+            if (work > most) most = work;
+        }
+        if (!cnt) continue;
+        hipLaunchKernelGGL(merkle_open_groups_kernel, dim3(grid_for(most), cnt), dim3(256), 0, (hipStream_t)stream, gs);
+        HIPCHK(hipGetLastError());
+    }
+    return TOYNI_OK;
 }
 
 // ---- plumbing ----
