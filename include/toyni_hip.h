@@ -331,6 +331,11 @@ int toyni_stream_create(void** stream, int device);
 int toyni_stream_destroy(void* stream);
 /* Ordering between two streams: what is enqueued on `stream` after this call runs after everything enqueued on `after` so far. */
 int toyni_stream_wait(void* stream, void* after);
+/* The same in two steps: mark a point of one stream now (toyni_event_record), make another stream wait for it later. */
+int toyni_event_create(void** event);
+int toyni_event_destroy(void* event);
+int toyni_event_record(void* event, void* stream);
+int toyni_stream_wait_event(void* stream, void* event);
 int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); with a context: also releases what that stream outgrew */
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);

@@ -467,6 +467,18 @@ def test_stream_plumbing_for_hosts_without_a_hip_binding(ta):
     assert lib.toyni_memcpy_d2h(out.ctypes.data, d, 8 * n) == 0
     assert (out[:n] == oracle.ntt(x.astype(np.uint64))).all() and (out[n:] == 0).all()
     assert lib.toyni_stream_wait(sa, sa) == 0                  # a stream waiting for itself is a no-op
+    # the two-step form: mark a point of A now, let B wait for it later
+    ev = ctypes.c_void_p()
+    assert lib.toyni_event_create(ctypes.byref(ev)) == 0
+    ctx.run_device(d.value, d.value, 1, True, stream=sa.value)                      # d[:n] back to x on A
+    assert lib.toyni_event_record(ev, sa) == 0
+    assert lib.toyni_memset_async(ctypes.c_void_p(d.value + 4 * n), 0xFF, 4 * n, sa) == 0   # later work on A that B does not wait for
+    assert lib.toyni_stream_wait_event(sb, ev) == 0
+    assert lib.toyni_memcpy_d2h_async(host.ctypes.data, d, 4 * n, sb) == 0
+    assert lib.toyni_stream_synchronize(None, sb) == 0 and lib.toyni_stream_synchronize(None, sa) == 0
+    assert (host[:n] == x).all()
+    assert lib.toyni_event_destroy(ev) == 0 and lib.toyni_event_destroy(None) == 0
+    assert lib.toyni_event_record(None, sa) == 10002 and lib.toyni_stream_wait_event(sb, None) == 10002
     ctx.destroy()
     pin.free()
     for p in (d, e):

@@ -127,6 +127,10 @@ SIGNATURES = {
     "toyni_stream_create": (c_int, [ctypes.POINTER(c_void_p), c_int]),
     "toyni_stream_destroy": (c_int, [c_void_p]),
     "toyni_stream_wait": (c_int, [c_void_p, c_void_p]),
+    "toyni_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "toyni_event_destroy": (c_int, [c_void_p]),
+    "toyni_event_record": (c_int, [c_void_p, c_void_p]),
+    "toyni_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
     "toyni_ntt_ctx_trim": (c_int, [c_void_p]),
     "toyni_set_device": (c_int, [c_int]),

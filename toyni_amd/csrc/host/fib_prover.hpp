@@ -154,6 +154,7 @@ class Prover {
         TOYNI_FIB_TRY(toyni_ntt_ctx_create((uint32_t)N_, device_, &ctx_N_), "LDE-domain context");
         TOYNI_FIB_TRY(toyni_stream_create(&stream_, toyni_ntt_ctx_device(ctx_N_)), "stream");
         TOYNI_FIB_TRY(toyni_stream_create(&side_, toyni_ntt_ctx_device(ctx_N_)), "stream");
+        TOYNI_FIB_TRY(toyni_event_create(&salts_ready_), "event");
         const size_t tree_bytes = toyni_merkle_total_digests(N_) * 32;
         salt_bytes_ = ((3 * N_ + salted_fri_) * 16 + 63) & ~(size_t)63;
         struct { void** p; size_t bytes; } bufs[] = {
@@ -190,7 +191,9 @@ class Prover {
         auto up = [&](void* d, const void* h, size_t bytes) { traffic_.h2d_bytes += bytes; ++traffic_.h2d_copies; return toyni_memcpy_h2d_async(d, h, bytes, s); };
         auto down = [&](void* h, const void* d, size_t bytes) { traffic_.d2h_bytes += bytes; ++traffic_.d2h_copies; return toyni_memcpy_d2h_async(h, d, bytes, s); };
         // every salt of the proof in one keystream: 3 LDE-size trees + the salted FRI layers (16 bytes per leaf, :341-343)
-        TOYNI_FIB_TRY(toyni_chacha20_fill_device(d_salts_, salt_bytes_, key, 0, s), "salts");
+        // (on the side stream: the 134 MB keystream is generated while the trace is uploaded, interpolated and extended)
+        TOYNI_FIB_TRY(toyni_chacha20_fill_device(d_salts_, salt_bytes_, key, 0, times ? s : side_), "salts");
+        TOYNI_FIB_TRY(toyni_event_record(salts_ready_, times ? s : side_), "event");
         const uint8_t* salts_trace = d_salts_;
         const uint8_t* salts_quot = d_salts_ + 16 * N_;
         const uint8_t* salts_deep = d_salts_ + 32 * N_;
@@ -244,6 +247,7 @@ class Prover {
         TOYNI_FIB_TRY(toyni_fib_quotient_device(ctx_N_, d_trace_lde_, d_c_, d_q_, LOG_BLOWUP, COSET_SHIFT, s), "constraint / quotient");
         TOYNI_FIB_TRY(toyni_coset_ntt_device(ctx_N_, d_c_, d_c_, 1, COSET_SHIFT, 1, s), "ifft (c_poly)");          // :145
         TOYNI_FIB_TRY(toyni_coset_ntt_device(ctx_N_, d_q_, d_qpoly_, 1, COSET_SHIFT, 1, s), "ifft (q_poly)");      // :151
+        TOYNI_FIB_TRY(toyni_stream_wait_event(s, salts_ready_), "stream order");   // the main stream's first use of the salts
         TOYNI_FIB_TRY(toyni_merkle_commit_device(d_q_, salts_quot, N_, d_quot_tree_, s), "quotient commitment");
         TOYNI_FIB_TRY(toyni_stream_wait(s, side_), "stream order");          // both trees are complete before their roots are read
         const size_t root_off = (toyni_merkle_total_digests(N_) - 1) * 32;
@@ -402,6 +406,7 @@ class Prover {
         if (h_pinned_) (void)toyni_host_free(h_pinned_);
         if (stream_) (void)toyni_stream_destroy(stream_);
         if (side_) (void)toyni_stream_destroy(side_);
+        if (salts_ready_) (void)toyni_event_destroy(salts_ready_);
         if (ctx_n_) (void)toyni_ntt_ctx_destroy(ctx_n_);
         if (ctx_N_) (void)toyni_ntt_ctx_destroy(ctx_N_);
     }
@@ -413,7 +418,7 @@ class Prover {
     Traffic traffic_;
     std::vector<size_t> sizes_;       // folded layer sizes N/2 ... final_size
     toyni_ntt_ctx *ctx_n_ = nullptr, *ctx_N_ = nullptr;
-    void *stream_ = nullptr, *side_ = nullptr;
+    void *stream_ = nullptr, *side_ = nullptr, *salts_ready_ = nullptr;
     uint32_t *d_compact_ = nullptr, *d_trace_lde_ = nullptr, *d_c_ = nullptr, *d_q_ = nullptr, *d_qpoly_ = nullptr, *d_deep_ = nullptr, *d_layers_ = nullptr,
              *d_ood_ = nullptr, *d_idx_ = nullptr;
     uint8_t *d_trace_tree_ = nullptr, *d_quot_tree_ = nullptr, *d_deep_tree_ = nullptr, *d_fri_trees_ = nullptr, *d_salts_ = nullptr, *d_records_ = nullptr;

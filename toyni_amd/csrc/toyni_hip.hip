@@ -2361,6 +2361,18 @@ int toyni_stream_wait(void* stream, void* after) {
     return (int)e;
 }
 
+// Events (timing disabled): record on one stream now, let another stream wait for that point later.
+int toyni_event_create(void** event) {
+    if (!event) return TOYNI_E_NULL;
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *event = (void*)ev;
+    return TOYNI_OK;
+}
+int toyni_event_destroy(void* event) { return event ? (int)hipEventDestroy((hipEvent_t)event) : TOYNI_OK; }
+int toyni_event_record(void* event, void* stream) { return event ? (int)hipEventRecord((hipEvent_t)event, (hipStream_t)stream) : TOYNI_E_NULL; }
+int toyni_stream_wait_event(void* stream, void* event) { return event ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) : TOYNI_E_NULL; }
+
 int toyni_stream_synchronize(toyni_ntt_ctx* c, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (c) {
