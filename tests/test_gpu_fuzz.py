@@ -2,6 +2,8 @@
 shifts, in place / out of place and chunking drawn from a seeded generator, so every run checks the same few hundred
 cases -- chosen to wander over the dispatch table's seams (1 / 2 / 3-pass plans, 8 / 16 / 32-wide tiles of the
 1024-point passes, ragged single-pass row tiles, batches that are not multiples of anything).  Bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,10 +26,12 @@ def _oracle_rows(x, n, inverse, shift):
 
 
 def test_random_shapes_against_oracle(ta):
-    rng = np.random.default_rng(0x70796E69)
+    # TOYNI_FUZZ_SEED / TOYNI_FUZZ_CASES: soak runs over other seeds and more cases (defaults: the fixed 220 of every run)
+    rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", str(0x70796E69)), 0))
     budget = 1 << 23                      # elements per case (oracle time stays in the tens of milliseconds)
     cases = 0
-    for _ in range(220):
+    ncases = int(os.environ.get("TOYNI_FUZZ_CASES", "220"))
+    for _ in range(ncases):
         log_n = int(rng.integers(0, 21))
         n = 1 << log_n
         max_batch = max(1, min(70, budget >> log_n))
@@ -58,7 +62,7 @@ def test_random_shapes_against_oracle(ta):
         assert (got.astype(np.uint64) == want).all(), \
             f"log_n={log_n} batch={batch} inverse={inverse} shift={shift} inplace={inplace} chunk={chunk}"
         cases += 1
-    assert cases == 220
+    assert cases == ncases
 
 
 def test_random_folds_against_oracle(ta):

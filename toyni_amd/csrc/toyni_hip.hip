@@ -881,8 +881,9 @@ int grow(toyni_ntt_ctx* c, hipStream_t s, void** buf, size_t* have, size_t need,
 void drop_retired_event(toyni_ntt_ctx* c, size_t index) {
     hipEvent_t ev = c->retired[index].ev;
     if (!ev) return;
+    c->retired[index].ev = nullptr;   // this entry no longer holds it: when all sharers go in one sweep, the last one still destroys it
     for (size_t j = 0; j < c->retired.size(); ++j)
-        if (j != index && c->retired[j].ev == ev) return;
+        if (c->retired[j].ev == ev) return;
     (void)hipEventDestroy(ev);
 }
 
