@@ -219,10 +219,18 @@ static void test_fold(int log_N, int layer, uint32_t shift) {
     const uint32_t x0 = (uint32_t)xs[0];
     f.coef = to_mont_host(bb_mul_host(bb_mul_host((uint32_t)beta, BB_HALF), bb_inv_host(x0)));
     f.half = half;
+    f.step = to_mont_host(bb_inv_host(bb_root_of_unity_host((uint32_t)(log_N - layer))));
     for (size_t i = 0; i < half; ++i) out[i] = fold_one(f, i, e32[i], e32[i + half]);
     size_t bad = 0;
     for (size_t i = 0; i < half; ++i) if (out[i] != (uint32_t)want[i]) ++bad;
     CHECK(bad == 0, "fold log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
+    for (size_t i = 0; i + 4 <= half; i += 4) {   // the four-outputs form of the large-layer stream: one lookup, three running products
+        const uint32_t a4[4] = {e32[i], e32[i + 1], e32[i + 2], e32[i + 3]}, b4[4] = {e32[i + half], e32[i + half + 1], e32[i + half + 2], e32[i + half + 3]};
+        uint32_t r4[4];
+        fold_quad(f, i, a4, b4, r4);
+        for (int j = 0; j < 4; ++j) if (r4[j] != (uint32_t)want[i + j]) ++bad;
+    }
+    CHECK(bad == 0, "fold_quad log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
 }
 
 static void test_fold_ext(size_t len) {

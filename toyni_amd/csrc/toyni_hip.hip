@@ -347,6 +347,51 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const FoldArgs f, const u
     }
 }
 
+// The plain fold of a large layer as a shaped stream (round 3): T-thread workgroups, U independent 16-byte load pairs in flight per
+// lane, a workgroup covering U * T consecutive quads per iteration -- the shape in which a copy reaches the box's 6.2 TB/s
+// (profiles/r03_copyceiling.txt: 1024 threads x 4 in flight) -- and one table lookup per four outputs (fold_quad).
+template <bool NT, int T, int U>
+__global__ void __launch_bounds__(T) fri_fold_stream_kernel(const FoldArgs f) {
+    const uint64_t quads = f.half / 4;
+    const uint4* ea = reinterpret_cast<const uint4*>(f.evals);
+    const uint4* eb = reinterpret_cast<const uint4*>(f.evals + f.half);
+    uint4* o = reinterpret_cast<uint4*>(f.out);
+    const uint64_t chunk = (uint64_t)U * T;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < quads; c0 += (uint64_t)gridDim.x * chunk) {
+        uint4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t q = c0 + (uint64_t)u * T + threadIdx.x;
+            if (q < quads) {
+                if constexpr (NT) {
+                    const u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ea + q));
+                    const u32x4 vb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(eb + q));
+                    a[u] = make_uint4(va.x, va.y, va.z, va.w);
+                    b[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
+                } else {
+                    a[u] = ea[q];
+                    b[u] = eb[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t q = c0 + (uint64_t)u * T + threadIdx.x;
+            if (q < quads) {
+                const uint32_t av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+                uint32_t r[4];
+                fold_quad(f, 4 * q, av, bv, r);
+                if constexpr (NT) {
+                    u32x4 vr = {r[0], r[1], r[2], r[3]};
+                    __builtin_nontemporal_store(vr, reinterpret_cast<u32x4*>(o + q));
+                } else {
+                    o[q] = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+    }
+}
+
 // ---- salts (prover_kernels.hpp: chacha20_block) ----
 struct ChaChaArgs {
     uint32_t key[8];
@@ -1767,6 +1812,11 @@ int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, ui
 }
 
 // ---- FRI fold ----
+static int fold_shape() {
+    static const int v = [] { const char* e = std::getenv("TOYNI_FOLD_SHAPE"); return e ? std::atoi(e) : 2; }();
+    return v;
+}
+
 static int fold_args(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, FoldArgs& f) {
     if (m % 2) return TOYNI_E_ODD_LENGTH;
     if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
@@ -1780,6 +1830,7 @@ static int fold_args(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out,
     f.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
+    f.step = to_mont_host(bb_inv_host(bb_root_of_unity_host((uint32_t)ilog2(m))));
     return TOYNI_OK;
 }
 
@@ -1795,6 +1846,25 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     if (d_leaves) {
         hipLaunchKernelGGL((fri_fold_kernel<false, true>), dim3(grid_for(work)), dim3(256), 0, s, f, reinterpret_cast<const uint4*>(d_salts),
                            reinterpret_cast<Digest*>(d_leaves));
+    } else if ((f.half & 3) == 0 && f.half >= ((uint64_t)1 << 16) && fold_shape() != 0) {
+        // large layers: the shaped stream.  TOYNI_FOLD_SHAPE (A/B knob) = 0: round 2's kernel; 1: 1024 threads x 4 in flight; 2 (default):
+        // 1024 x 2; 3: 512 x 4; 4: 256 x 4.  Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for the
+        // round-2 kernel, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4.
+        const bool nt = (uint64_t)m * sizeof(uint32_t) >= nt_min_bytes();
+        const uint64_t quads = f.half / 4;
+        auto grid = [&](uint64_t chunk) { uint64_t g = (quads + chunk - 1) / chunk; const uint64_t cap = (uint64_t)c->num_cus * 8; return (unsigned)(g > cap ? cap : g); };
+#define TOYNI_FOLD_GO(T_, U_)                                                                                                         \
+    do {                                                                                                                              \
+        if (nt) hipLaunchKernelGGL((fri_fold_stream_kernel<true, T_, U_>), dim3(grid((uint64_t)T_ * U_)), dim3(T_), 0, s, f);         \
+        else hipLaunchKernelGGL((fri_fold_stream_kernel<false, T_, U_>), dim3(grid((uint64_t)T_ * U_)), dim3(T_), 0, s, f);           \
+    } while (0)
+        switch (fold_shape()) {
+            case 1: TOYNI_FOLD_GO(1024, 4); break;
+            case 2: TOYNI_FOLD_GO(1024, 2); break;
+            case 3: TOYNI_FOLD_GO(512, 4); break;
+            default: TOYNI_FOLD_GO(256, 4); break;
+        }
+#undef TOYNI_FOLD_GO
     } else if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) {
         hipLaunchKernelGGL((fri_fold_kernel<true, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     } else {
