@@ -38,7 +38,7 @@ def counter_mean(sub, counter, keep):
     return {k: (sum(v) / len(v), len(v), max(v)) for k, v in agg.items()}
 
 
-fold = lambda name: "fri_fold_kernel" in name  # noqa: E731
+fold = lambda name: "fri_fold_kernel" in name or "fri_fold_stream_kernel" in name  # noqa: E731
 rows = stats_rows("fold_stats", fold)
 fetch, write = counter_mean("fold_fetch", "FETCH_SIZE", fold), counter_mean("fold_write", "WRITE_SIZE", fold)
 with open(f"profiles/{tag}_fold_stats.csv", "w", newline="") as out:
