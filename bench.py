@@ -149,8 +149,32 @@ def bench_fourstep(args, dev, rank, world, distributed):
     fence()
     wall = tdist.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.equal(back, keep), "round trip changed the data"
+    # A round trip is the identity for many wrong exchanges too: the FORWARD half is gathered on rank 0 and compared with the
+    # single-device transform of the gathered input (the first run on real links checks itself; outside the timed region).
+    fwd = tdist.slab_forward(keep.clone(), log_n, ops, rank, world, chunks=args.chunks) if slab else tdist.fourstep_forward(keep, log_n, ops, rank, world)
+    ins = [torch.empty_like(keep) for _ in range(world)]
+    outs = [torch.empty_like(fwd) for _ in range(world)]
+    if distributed:
+        dist.all_gather(ins, keep.contiguous())
+        dist.all_gather(outs, fwd.contiguous())
+    else:
+        ins, outs = [keep], [fwd]
+    verified = None
+    if rank == 0:
+        in_index = tdist.slab_input_index if slab else tdist.fourstep_input_index
+        out_index = tdist.slab_output_index if slab else tdist.fourstep_output_index
+        x = torch.empty(1 << log_n, dtype=torch.int32, device=dev)
+        for g in range(world):
+            x[in_index(log_n, world, g).to(dev).reshape(-1)] = ins[g].reshape(-1)
+        ops.big.run_device(x.data_ptr(), x.data_ptr(), 1, False, stream=torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        verified = all(torch.equal(outs[h].reshape(-1), x[out_index(log_n, world, h).to(dev).reshape(-1)]) for h in range(world))
+        assert verified, "the distributed forward transform differs from the single-device transform"
+        del x
+    del ins, outs, fwd
     if rank == 0:
         print(json.dumps({
+            "exchange_verified": verified,
             "metric": "BabyBear NTT throughput, single transform split over GPUs (%s, one all-to-all)" % ("slab form" if slab else "4-step"), "value": 2 * args.steps * (1 << log_n) / wall,
             "unit": "elements/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
             "collective_backend": dist.get_backend() if distributed else None,

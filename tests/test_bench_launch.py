@@ -65,12 +65,14 @@ def test_two_ranks_on_one_gpu_rehearsal():
     the batch workload and the slab workload (one all-to-all per transform)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["TOYNI_BENCH_BACKEND"] = "gloo"
-    for extra in (["--batch", "8"], ["--workload", "slab", "--log-n", "22"]):
+    for extra in (["--batch", "8"], ["--workload", "slab", "--log-n", "22"], ["--workload", "fourstep", "--log-n", "20"]):
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                               "--no-extras", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
         out = _last_json(res.stdout)
         assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+        if "--workload" in extra:    # the forward half was gathered and compared with the single-device transform
+            assert out["exchange_verified"] is True
         if "--batch" in extra:       # the per-rank table: which device every rank used and its own step time
             assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["ms_per_step"] > 0 and r["transforms_per_step"] == 16 for r in out["ranks"])
             assert "rank  device  pci" in res.stderr
