@@ -92,7 +92,9 @@ int main() {
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,lde,folds,final", [(64, 2048, 8, 8), (8, 256, 8, 1), (1 << 16, 1 << 21, 17, 16)])
+@pytest.mark.parametrize("n,lde,folds,final", [(64, 2048, 8, 8), (8, 256, 8, 1), (1 << 16, 1 << 21, 17, 16),
+                                               # in between: masks longer than the trace (n < 140), and every plan the LDE sizes 2^9 .. 2^19 take
+                                               (16, 512, 8, 2), (128, 4096, 9, 8), (256, 8192, 9, 16), (1024, 1 << 15, 11, 16), (1 << 14, 1 << 19, 15, 16)])
 def test_cpp_proof_is_accepted_by_the_verifier_restatement(tmp_path, n, lde, folds, final):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
