@@ -716,17 +716,17 @@ def main():
                 # inversion chain per 4 outputs, so the bound is VALU, not HBM: 8 B per input element (4 evals + 2 xs read, 2 written)
                 xs24 = torch.randint(1, P, (nn // 2,), dtype=torch.int32, device=dev)
                 t_xs = time_dev(lambda: toyni_amd.fri_fold_xs_device(p1, xs24.data_ptr(), o.data_ptr(), nn, 123456789, stream=stream), 20)
-                # ~31 squarings + ~15 multiplies of the shared inversion chain per 4 outputs plus 3 products each to split it (Montgomery's
-                # trick) and the fold itself: ~70 mont_mul-class products per 4 outputs = 17.5 per output = 8.75 per input element, 5 VALU
-                # instructions each, against the 39.3 T lane-ops/s of that instruction class
-                xs_lane_ops = 8.75 * 5 + 10
+                # round 3 (fold_xs_batch): 46 products of the shared inversion per SIXTEEN outputs plus 6 per output (to Montgomery form,
+                # prefix product, two for the back-substitution, the coefficient, the application): ~9 per output = 4.5 per input element,
+                # 5 VALU instructions each, plus the adds, against the 39.3 T lane-ops/s of that instruction class
+                xs_lane_ops = 4.5 * 5 + 8
                 extras["fri_fold_xs_m2^24"] = {
                     "us": t_xs * 1e6, "GBps": 8.0 * nn / t_xs / 1e9, "frac_of_hbm_peak": 8.0 * nn / t_xs / 1e9 / HBM_PEAK_GBPS,
                     "elements_per_s": nn / t_xs, "bound": "valu",
                     "valu": {"lane_ops_per_input_element_estimate": xs_lane_ops, "achieved_Tops_estimate": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
                              "frac_estimate": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
                     "note": "toyni_fri_fold_xs_device on a 2^24 layer, explicit points resident in HBM; 8 B algorithmic per input element (4 evals + 2 xs "
-                            "read, 2 written); bound by the per-4-outputs Fermat inversion (src/math/fri.rs:38-40 inverts per element), not by HBM"}
+                            "read, 2 written); one Fermat inversion per 16 outputs (src/math/fri.rs:38-40 inverts per element); round 2's 4-per-inversion kernel moved 3.0 TB/s"}
                 del xs24
             # reference-shaped host-slice entry point (PCIe inclusive; never `value`)
             h = np.random.default_rng(1).integers(0, P, nn, dtype=np.uint64)

@@ -233,6 +233,35 @@ static void test_fold(int log_N, int layer, uint32_t shift) {
     CHECK(bad == 0, "fold_quad log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
 }
 
+// fold_xs_batch (16 outputs behind one inversion, Montgomery form throughout) against the oracle's fri_fold on explicit points,
+// with zero points inside a batch (their own inverse is 0; their neighbours' must be untouched)
+static void test_fold_xs_batch() {
+    const size_t m = 64, half = m / 2;
+    std::vector<uint64_t> evals(m), xs(m), want(half);
+    orc_fill_splitmix(evals.data(), m, 4242);
+    orc_fill_splitmix(xs.data(), m, 4343);
+    for (size_t i = 0; i < m; ++i) if (xs[i] == 0) xs[i] = 1;
+    const uint64_t beta = 987654321;
+    orc_fri_fold(want.data(), evals.data(), m, xs.data(), beta);
+    const uint32_t beta_half_R = to_mont_host(bb_mul_host((uint32_t)beta, BB_HALF));
+    size_t bad = 0;
+    for (size_t g = 0; g < half / 16; ++g) {
+        uint32_t x[16], a[16], b[16], r[16];
+        for (int j = 0; j < 16; ++j) { x[j] = (uint32_t)xs[16 * g + j]; a[j] = (uint32_t)evals[16 * g + j]; b[j] = (uint32_t)evals[16 * g + j + half]; }
+        fold_xs_batch<16>(x, a, b, beta_half_R, r);
+        for (int j = 0; j < 16; ++j) bad += r[j] != (uint32_t)want[16 * g + j];
+        // zero points at positions 3 and 15: their outputs are the plain average, everyone else's are unchanged
+        x[3] = 0; x[15] = 0;
+        uint32_t rz[16];
+        fold_xs_batch<16>(x, a, b, beta_half_R, rz);
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t avg = bb_halve(bb_add(a[j], b[j]));
+            bad += (j == 3 || j == 15) ? rz[j] != avg : rz[j] != r[j];
+        }
+    }
+    CHECK(bad == 0, "fold_xs_batch: %zu mismatches", bad);
+}
+
 static void test_fold_ext(size_t len) {
     const size_t half = len / 2;
     std::vector<uint64_t> evals(4 * len), xs(len), want(4 * half);
@@ -606,6 +635,7 @@ int main(int argc, char** argv) {
     test_fold(6, 2, 1);
     for (size_t n : {1, 2, 3, 4, 5, 8, 100, 1024}) { test_merkle(n, false); test_merkle(n, true); }
     test_merkle_coop();
+    test_fold_xs_batch();
     test_prover_steps(6, 2, 7);
     test_prover_steps(9, 5, 7);
     test_prover_steps(8, 3, 1234567);

@@ -1284,4 +1284,37 @@ TOYNI_HD uint32_t bb_inv_dev(uint32_t a) {
     return from_mont(r);
 }
 
+
+// B outputs of the explicit-point fold behind ONE Fermat inversion (round 3; the 4-per-inversion kernel above stays for ragged tails):
+// everything in Montgomery form -- x_j R once, prefix products, (prod x)^-1 R by mont_inv-style exponentiation, back-substitution --
+// so an output costs 6 Montgomery products plus 1/B of the 46 of the inversion (B = 16: ~9) where the round-2 kernel spent ~20
+// (its products went through plain form, two reductions each, and four outputs shared an inversion).  A zero point rides along as
+// 1 and gets inverse 0 = pow(0, p - 2), exactly as in fri_fold_xs_kernel.  r[j] = (a_j + b_j)/2 + (a_j - b_j) (beta/2) / x_j.
+template <int B>
+TOYNI_HD void fold_xs_batch(const uint32_t (&x)[B], const uint32_t (&a)[B], const uint32_t (&b)[B], uint32_t beta_half_R, uint32_t (&r)[B]) {
+    uint32_t xR[B], pre[B];
+    bool zero[B];
+    uint32_t acc = BB_R1;                        // Montgomery one
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        zero[j] = x[j] == 0u;
+        xR[j] = zero[j] ? BB_R1 : to_mont(x[j]);
+        pre[j] = acc;                            // (x_0 .. x_{j-1}) R
+        acc = mont_mul(acc, xR[j]);
+    }
+    uint32_t inv = BB_R1, base = acc, e = BB_P - 2u;   // (prod x)^-1 R: a^(p-2), src/babybear.rs:111-114
+    for (int i = 0; i < 31; ++i) {
+        if (e & 1u) inv = mont_mul(inv, base);
+        base = mont_mul(base, base);
+        e >>= 1;
+    }
+#pragma unroll
+    for (int j = B - 1; j >= 0; --j) {
+        const uint32_t xinvR = zero[j] ? 0u : mont_mul(inv, pre[j]);   // x_j^-1 R
+        inv = mont_mul(inv, xR[j]);
+        const uint32_t cwR = mont_mul(xinvR, beta_half_R);             // (beta/2) x_j^-1 R
+        r[j] = bb_add(bb_halve(bb_add(a[j], b[j])), mont_mul(bb_sub_lazy(a[j], b[j]), cwR));
+    }
+}
+
 }  // namespace toyni

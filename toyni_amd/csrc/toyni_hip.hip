@@ -550,6 +550,29 @@ __global__ void __launch_bounds__(256) merkle_open_groups_kernel(const OpenGroup
     merkle_open_group(gs.g[blockIdx.y], (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
+// FRI fold, explicit points, 16 outputs per thread and per Fermat inversion (fold_xs_batch), 16-byte accesses; half a multiple of 16
+__global__ void __launch_bounds__(256) fri_fold_xs16_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
+                                                             uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half_R) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint4* ea = reinterpret_cast<const uint4*>(evals);
+    const uint4* eb = reinterpret_cast<const uint4*>(evals + half);
+    const uint4* xp = reinterpret_cast<const uint4*>(xs);
+    uint4* o = reinterpret_cast<uint4*>(out);
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < half / 16; g += stride) {
+        uint32_t x[16], a[16], b[16], r[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 xv = xp[4 * g + q], av = ea[4 * g + q], bv = eb[4 * g + q];
+            x[4 * q] = xv.x; x[4 * q + 1] = xv.y; x[4 * q + 2] = xv.z; x[4 * q + 3] = xv.w;
+            a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
+            b[4 * q] = bv.x; b[4 * q + 1] = bv.y; b[4 * q + 2] = bv.z; b[4 * q + 3] = bv.w;
+        }
+        fold_xs_batch<16>(x, a, b, beta_half_R, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[4 * g + q] = make_uint4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    }
+}
+
 // FRI fold, explicit points: 4 inversions share one Fermat exponentiation (Montgomery's trick)
 __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
                                                            uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half_R) {
@@ -1924,7 +1947,15 @@ int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint
     if (beta >= BB_P) return TOYNI_E_RANGE;
     const uint64_t half = m / 2;
     const uint32_t beta_half_R = to_mont_host(bb_mul_host(beta, BB_HALF));
-    hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
+    // large layers of whole 16-output groups behind 16-byte aligned pointers: one inversion per 16 outputs.  Measured, alternating
+    // (profiles/r03_ab_fold_xs16.txt): 2^24 layer 46.6 -> 26.7 us (2.9 -> 5.0 TB/s of its 8 B per input element), 2^27 418 -> 238 us;
+    // a 2^20 layer LOSES (6.8 -> 9.0 us: 32 768 threads with a four times longer serial chain each), hence the size gate.
+    // TOYNI_FOLD_XS16=0: always the 4-per-inversion kernel (A/B).
+    static const bool xs16 = [] { const char* e = std::getenv("TOYNI_FOLD_XS16"); return !(e && e[0] == '0'); }();
+    if (xs16 && half >= ((uint64_t)1 << 21) && (half & 15) == 0 && !(((uintptr_t)d_evals | (uintptr_t)d_xs | (uintptr_t)d_out) & 15))
+        hipLaunchKernelGGL(fri_fold_xs16_kernel, dim3(grid_for(half / 16)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
+    else
+        hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
     return (int)hipGetLastError();
 }
 
