@@ -633,6 +633,52 @@ __global__ void __launch_bounds__(256) fri_fold_ext_kernel(const FoldExtArgs fa)
     }
 }
 
+// The same for large layers in the shape of fri_fold_stream_kernel: T-thread workgroups, U load pairs in flight per lane, U * T
+// consecutive elements per workgroup and iteration, non-temporal when the layer is far larger than the Infinity Cache.
+template <bool NT, int T, int U>
+__global__ void __launch_bounds__(T) fri_fold_ext_stream_kernel(const FoldExtArgs fa) {
+    const FoldArgs& f = fa.base;
+    const uint64_t half = f.half;
+    const uint4* ea = reinterpret_cast<const uint4*>(f.evals);
+    const uint4* eb = ea + half;
+    uint4* o = reinterpret_cast<uint4*>(f.out);
+    const uint64_t chunk = (uint64_t)U * T;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < half; c0 += (uint64_t)gridDim.x * chunk) {
+        uint4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = c0 + (uint64_t)u * T + threadIdx.x;
+            if (i < half) {
+                if constexpr (NT) {
+                    const u32x4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ea + i));
+                    const u32x4 vb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(eb + i));
+                    a[u] = make_uint4(va.x, va.y, va.z, va.w);
+                    b[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
+                } else {
+                    a[u] = ea[i];
+                    b[u] = eb[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = c0 + (uint64_t)u * T + threadIdx.x;
+            if (i < half) {
+                const uint32_t e = (uint32_t)(i << f.log_step);
+                const uint32_t w = mont_mul(f.inv_hi[e >> f.lowbits], f.inv_lo[e & ((1u << f.lowbits) - 1)]);
+                const uint32_t scaleR = mont_mul(w, f.coef);
+                const Ext4 r = fold_ext_one(Ext4{{a[u].x, a[u].y, a[u].z, a[u].w}}, Ext4{{b[u].x, b[u].y, b[u].z, b[u].w}}, scaleR, fa.beta_half);
+                if constexpr (NT) {
+                    u32x4 vr = {r.c[0], r.c[1], r.c[2], r.c[3]};
+                    __builtin_nontemporal_store(vr, reinterpret_cast<u32x4*>(o + i));
+                } else {
+                    o[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
+                }
+            }
+        }
+    }
+}
+
 // explicit base-field points (the reference's signature fri_fold_ext(evals, xs, beta))
 __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __restrict__ evals, const uint32_t* __restrict__ xs,
                                                                uint4* __restrict__ out, uint64_t half, const ExtFactor beta_half) {
@@ -1869,7 +1915,9 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     if (d_leaves) {
         hipLaunchKernelGGL((fri_fold_kernel<false, true>), dim3(grid_for(work)), dim3(256), 0, s, f, reinterpret_cast<const uint4*>(d_salts),
                            reinterpret_cast<Digest*>(d_leaves));
-    } else if ((f.half & 3) == 0 && f.half >= ((uint64_t)1 << 16) && fold_shape() != 0) {
+    } else if ((f.half & 3) == 0 && m >= ((uint64_t)1 << 26) && fold_shape() != 0) {
+        // (layers of >= 256 MiB: measured +22 % at 2^26 and +10 % at 2^27 elements; a cache-resident 2^24 layer is 5 % FASTER on the
+        // 256-thread kernel below -- 5.95 against 5.63 TB/s -- so smaller layers keep it)
         // large layers: the shaped stream.  TOYNI_FOLD_SHAPE (A/B knob) = 0: round 2's kernel; 1: 1024 threads x 4 in flight; 2 (default):
         // 1024 x 2; 3: 512 x 4; 4: 256 x 4.  Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for the
         // round-2 kernel, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4.
@@ -1987,6 +2035,15 @@ int toyni_fri_fold_ext_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_
     fa.base.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
     fa.base.coef = to_mont_host(bb_inv_host(x0));
     fa.base.half = m / 2;
+    // streaming layers (>= TOYNI_NT_MIN_BYTES = 512 MiB of input): the shaped stream, 5.0-5.2 -> 6.0 TB/s on a 2^25-element layer; a
+    // cache-resident 2^22-element layer is faster on the 256-thread kernel (6.2 against 4.8 TB/s: profiles/r03_ab_fold_ext_shape.txt)
+    if ((uint64_t)m * 16 >= nt_min_bytes() && fold_shape() != 0) {
+        const uint64_t chunk = 2 * 1024, cap = (uint64_t)c->num_cus * 8;
+        uint64_t g = (fa.base.half + chunk - 1) / chunk;
+        if (g > cap) g = cap;
+        hipLaunchKernelGGL((fri_fold_ext_stream_kernel<true, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, (hipStream_t)stream, fa);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(fri_fold_ext_kernel, dim3(grid_for(fa.base.half)), dim3(256), 0, (hipStream_t)stream, fa);
     return (int)hipGetLastError();
 }
