@@ -255,10 +255,13 @@ def generate_proof(trace_col: np.ndarray, seed: int = 0, stats: dict = None, tim
     sizes = [ix.size * pv.merkle_open_record_bytes(t.n) for t, ix in groups]
     out = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
     ioff = boff = 0
+    batch = []
     for (t, ix), sz in zip(groups, sizes):
-        t.open_into(d_idx.data_ptr() + 4 * ioff, ix.size, out.data_ptr() + boff, stream)
+        batch.append((t.levels.data_ptr(), t.n, t.values.data_ptr(), t.salts.data_ptr() if t.salts is not None else 0,
+                      d_idx.data_ptr() + 4 * ioff, ix.size, out.data_ptr() + boff))
         ioff += ix.size
         boff += sz
+    pv.merkle_open_groups_device(batch, stream=stream)            # every tree's openings: one launch (round 2: one per tree)
     records = out.cpu().numpy()
     lap("7_queries")
     if stats is not None:

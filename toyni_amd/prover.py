@@ -71,6 +71,18 @@ def merkle_open_device(d_levels: int, n: int, d_values: int, d_salts: int, d_ind
     check(lib.toyni_merkle_open_device(d_levels, n, d_values, d_salts or None, d_indices, nidx, d_out, stream or None), "GPU Merkle opening failed")
 
 
+class _OpenGroup(ctypes.Structure):   # toyni_merkle_open_group (include/toyni_hip.h 3c)
+    _fields_ = [("d_levels", ctypes.c_void_p), ("n", ctypes.c_size_t), ("d_values", ctypes.c_void_p), ("d_salts", ctypes.c_void_p),
+                ("d_indices", ctypes.c_void_p), ("nidx", ctypes.c_size_t), ("d_out", ctypes.c_void_p)]
+
+
+def merkle_open_groups_device(groups, stream: int = 0) -> None:
+    """The openings of several trees in one launch per 32 trees.  groups: iterable of (d_levels, n, d_values, d_salts, d_indices, nidx,
+    d_out), every field as in merkle_open_device."""
+    arr = (_OpenGroup * len(groups))(*[_OpenGroup(lv, n, v, s or None, ix, k, o) for lv, n, v, s, ix, k, o in groups])
+    check(lib.toyni_merkle_open_groups_device(arr, len(groups), stream or None), "GPU Merkle openings failed")
+
+
 def parse_openings(raw: np.ndarray, n: int, indices, salted: bool):
     """Records of toyni_merkle_open_device -> the fields of MerkleOpening (src/fibonacci.rs:366-375)."""
     depth = 0
