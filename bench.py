@@ -110,6 +110,30 @@ def cpu_baseline(log_n, seconds):
     }
 
 
+def gather_rank_table(torch, dist, dev, coll_dev, rank, world, distributed, units, wall_s, steps, backend):
+    """(rank, device ordinal, PCI id, uuid tag, work units per step, own ms/step) of every rank, gathered on all ranks; rank 0 prints it and
+    asserts under RCCL that `world` ranks sit on `world` different GPUs."""
+    import zlib
+    prop = torch.cuda.get_device_properties(dev)
+    uuid_tag = zlib.crc32(str(getattr(prop, "uuid", "")).encode())      # a second identity next to the PCI id (either one distinct = distinct GPUs)
+    mine = torch.tensor([rank, dev.index, getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
+                         units, int(wall_s * 1e9), uuid_tag], dtype=torch.int64, device=coll_dev)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    if distributed:
+        dist.all_gather(table, mine)
+    else:
+        table = [mine]
+    rows = [{"rank": int(t[0]), "device": int(t[1]), "pci": "%04x:%02x:%02x" % (int(t[2]), int(t[3]) & 0xFF, int(t[4]) & 0xFF),
+             "uuid_crc32": "%08x" % int(t[7]), "units_per_step": int(t[5]), "ms_per_step": int(t[6]) / 1e6 / steps} for t in table]
+    if rank == 0 and distributed:
+        print("rank  device  pci           units/step  ms/step", file=sys.stderr)
+        for r in rows:
+            print("%4d  %6d  %-12s  %10d  %.3f" % (r["rank"], r["device"], r["pci"], r["units_per_step"], r["ms_per_step"]), file=sys.stderr)
+        if backend == "nccl":
+            assert len({(r["pci"], r["uuid_crc32"]) for r in rows}) == world, f"{world} ranks share GPUs: {rows}"
+    return rows
+
+
 def bench_fourstep(args, dev, rank, world, distributed):
     """One size-n transform over all ranks: local column transforms + twiddle, ONE all-to-all (RCCL), local row transforms."""
     import torch
@@ -147,8 +171,11 @@ def bench_fourstep(args, dev, rank, world, distributed):
     for _ in range(args.steps):
         back = step()
     fence()
-    wall = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    own_wall = time.perf_counter() - t0
+    wall = tdist.max_over_ranks(own_wall, dev)
     assert torch.equal(back, keep), "round trip changed the data"
+    backend = os.environ.get("TOYNI_BENCH_BACKEND", "nccl")
+    ranks_table = gather_rank_table(torch, dist if distributed else None, dev, dev, rank, world, distributed, 2, own_wall, args.steps, backend)
     # A round trip is the identity for many wrong exchanges too: the FORWARD half is gathered on rank 0 and compared with the
     # single-device transform of the gathered input (the first run on real links checks itself; outside the timed region).
     fwd = tdist.slab_forward(keep.clone(), log_n, ops, rank, world, chunks=args.chunks) if slab else tdist.fourstep_forward(keep, log_n, ops, rank, world)
@@ -174,7 +201,7 @@ def bench_fourstep(args, dev, rank, world, distributed):
     del ins, outs, fwd
     if rank == 0:
         print(json.dumps({
-            "exchange_verified": verified,
+            "exchange_verified": verified, "ranks": ranks_table,
             "metric": "BabyBear NTT throughput, single transform split over GPUs (%s, one all-to-all)" % ("slab form" if slab else "4-step"), "value": 2 * args.steps * (1 << log_n) / wall,
             "unit": "elements/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1,
             "collective_backend": dist.get_backend() if distributed else None,
@@ -574,24 +601,8 @@ def main():
     # Which device did every rank really run on?  (rank, device ordinal, PCI domain / bus / device, its transforms, its wall time):
     # rank 0 checks that N ranks sat on N different GPUs (under RCCL; the gloo rehearsal shares devices on purpose) and prints the
     # per-rank step times next to the maximum that `value` is computed from.
-    prop = torch.cuda.get_device_properties(dev)
-    import zlib
-    uuid_tag = zlib.crc32(str(getattr(prop, "uuid", "")).encode())      # a second identity next to the PCI id (either one distinct = distinct GPUs)
-    mine = torch.tensor([rank, dev.index, getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", -1), getattr(prop, "pci_device_id", -1),
-                         batch, int(wall * 1e9), uuid_tag], dtype=torch.int64, device=coll_dev)
-    table = [torch.zeros_like(mine) for _ in range(world)]
-    if distributed:
-        dist.all_gather(table, mine)
-    else:
-        table = [mine]
-    ranks_table = [{"rank": int(t[0]), "device": int(t[1]), "pci": "%04x:%02x:%02x" % (int(t[2]), int(t[3]) & 0xFF, int(t[4]) & 0xFF),
-                    "uuid_crc32": "%08x" % int(t[7]), "transforms_per_step": 2 * int(t[5]), "ms_per_step": int(t[6]) / 1e6 / args.steps} for t in table]
-    if rank == 0 and distributed:
-        print("rank  device  pci           transforms/step  ms/step", file=sys.stderr)
-        for r in ranks_table:
-            print("%4d  %6d  %-12s  %15d  %.3f" % (r["rank"], r["device"], r["pci"], r["transforms_per_step"], r["ms_per_step"]), file=sys.stderr)
-        if backend == "nccl":
-            assert len({(r["pci"], r["uuid_crc32"]) for r in ranks_table}) == world, f"{world} ranks share GPUs: {ranks_table}"
+    rows = gather_rank_table(torch, dist if distributed else None, dev, coll_dev, rank, world, distributed, 2 * batch, wall, args.steps, backend)
+    ranks_table = [dict(r, transforms_per_step=r["units_per_step"]) for r in rows]
     total_batch = sum(r["transforms_per_step"] for r in ranks_table) // 2
     transforms = 2 * total_batch * args.steps
     value = transforms * n / wall_max
