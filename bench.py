@@ -386,8 +386,8 @@ class ToolsLib:
 
 def profile_provenance(path):
     """Which commit produced a committed profile, and whether the kernels have changed since: (short hash of the last commit that
-    touched `path`, True if toyni_amd/csrc has commits after it).  (None, None) outside a git checkout (the GPU box gets a snapshot
-    without .git: there profiles/PROVENANCE.json, written by tools/stamp_profiles.py at commit time, answers instead)."""
+    touched `path`, True if toyni_amd/csrc has commits after it).  Profiles collected since round 3 carry the sha256 of the sources they
+    measured, which needs no git; for older ones the git history answers, and (None, None) comes back where there is no .git (the GPU box)."""
     import subprocess
     rel = os.path.relpath(path, ROOT)
     # 1. exact: the profile carries the sha256 of the sources it measured (tools/csrc_hash.py, recorded on the box at collection time)
@@ -403,7 +403,7 @@ def profile_provenance(path):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from csrc_hash import csrc_sha256
         return "sources sha256 " + measured[:12], measured != csrc_sha256()
-    # 2. fallback for older profiles: git history, or profiles/PROVENANCE.json where there is no .git
+    # 2. fallback for older profiles: git history
     try:
         h = subprocess.run(["git", "log", "-1", "--format=%h", "--", rel], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
         if h:
@@ -412,11 +412,6 @@ def profile_provenance(path):
             return h, bool(newer)
     except (OSError, subprocess.SubprocessError):
         pass
-    pj = os.path.join(ROOT, "profiles", "PROVENANCE.json")
-    if os.path.exists(pj):
-        ent = json.load(open(pj)).get(rel)
-        if ent:
-            return ent.get("commit"), ent.get("csrc_changed_since")
     return None, None
 
 
