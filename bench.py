@@ -110,6 +110,49 @@ def cpu_baseline(log_n, seconds):
     }
 
 
+XGMI_LINK_GBPS, XGMI_LINKS = 153.0, 7   # per GPU: 7 point-to-point xGMI links of ~153 GB/s (task brief; MI355X_MICROARCH.md has no xGMI row)
+
+
+def single_transform_cpu_baseline(log_n, seconds=6.0):
+    """cpu_baseline object of the one-large-transform workloads: the oracle's forward + inverse at n on one thread -- measured at n
+    itself up to 2^24 (a repetition takes ~4 s there), beyond that the 2^24 figure scaled by n log n and LABELLED as extrapolated
+    (a 2^27 repetition would take ~40 s of a run that must finish in minutes)."""
+    import subprocess
+    exe = _oracle_bench_binary()
+    lg = min(log_n, 24)
+    o = subprocess.run([exe, "ntt", str(lg), str(seconds)], capture_output=True, text=True, check=True).stdout.split()
+    reps, el = int(o[2]), float(o[3])
+    rate = 2 * reps * (1 << lg) / el
+    out = {"value": rate, "unit": "elements/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+           "sample": f"{reps} x (forward + inverse) NTT n=2^{lg} on 1 thread, {el:.1f} s (oracle/bench_oracle.c, gcc -O3 -march=native)"}
+    if lg != log_n:
+        out["value"] = rate * lg / log_n
+        out["extrapolated"] = True
+        out["sample"] += f"; EXTRAPOLATED to n=2^{log_n} by n log n (x {lg}/{log_n} in elements/s): not measured at that size"
+    return out
+
+
+def multi_device_roofline(log_n, lanes, n_devices, step_s, phases_ms, exchange_kind):
+    """roofline object of the one-transform-over-G-lanes workloads.  Algorithmic bytes: 8 B per element per transform
+    (as everywhere), two transforms per step, against the HBM of the devices in use.  Exchange: what one rank sends (= receives) per
+    transform -- its n / G words minus the block that stays -- against the xGMI links of one GPU."""
+    n = 1 << log_n
+    alg = 2 * 8.0 * n
+    achieved = alg / step_s / 1e9
+    ex_bytes = 4.0 * n / lanes * (lanes - 1) / lanes
+    ex_ms = (phases_ms or {}).get("exchange")
+    ex = {"bytes_sent_per_rank_per_transform": ex_bytes, "kind": exchange_kind,
+          "peak_GBps_per_gpu": XGMI_LINK_GBPS * XGMI_LINKS, "peak_note": f"{XGMI_LINKS} xGMI links x ~{XGMI_LINK_GBPS:.0f} GB/s per GPU, point to point: one peer's block rides ONE link",
+          "ms_per_step": ex_ms, "achieved_GBps_per_rank": (2 * ex_bytes / (ex_ms * 1e-3) / 1e9) if ex_ms else None,
+          "frac": (2 * ex_bytes / (ex_ms * 1e-3) / 1e9 / (XGMI_LINK_GBPS * XGMI_LINKS)) if ex_ms else None}
+    if n_devices == 1:
+        ex["note"] = "all lanes on ONE device: the exchange is device-local copies (a rehearsal of the control flow, not a link measurement)"
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * n_devices, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * n_devices),
+            "algorithmic_bytes_per_step": alg, "traffic": None,
+            "phases_ms_per_step": phases_ms, "phases_source": "HIP events on the launch stream between the stages of 3 extra steps after the timed region (rank 0)" if phases_ms else None,
+            "exchange": ex}
+
+
 def gather_rank_table(torch, dist, dev, coll_dev, rank, world, distributed, units, wall_s, steps, backend):
     """(rank, device ordinal, PCI id, uuid tag, work units per step, own ms/step) of every rank, gathered on all ranks; rank 0 prints it and
     asserts under RCCL that `world` ranks sit on `world` different GPUs."""
@@ -199,6 +242,28 @@ def bench_fourstep(args, dev, rank, world, distributed):
         assert verified, "the distributed forward transform differs from the single-device transform"
         del x
     del ins, outs, fwd
+    # per-phase times (slab pass / exchange / relayout / rows ...): three more steps with a HIP event between the stages, every rank
+    # runs them (the exchange is collective), rank 0 reports its own
+    phases = None
+    if args.chunks <= 1 or not slab:
+        clock = tdist.PhaseClock(dev)
+        psteps = 3
+        cur = keep.clone()
+        for _ in range(psteps):
+            if slab:
+                out_p = tdist.slab_forward(cur, log_n, ops, rank, world, clock=clock)
+                cur = tdist.slab_inverse(out_p, log_n, ops, rank, world, clock=clock)
+            else:
+                out_p = tdist.fourstep_forward(cur, log_n, ops, rank, world, clock=clock)
+                cur = tdist.fourstep_inverse(out_p, log_n, ops, rank, world, clock=clock)
+        phases = {k: v / psteps for k, v in clock.ms().items()}
+        del cur
+    roof, base = None, None
+    if rank == 0:
+        roof = multi_device_roofline(log_n, world, len({r["pci"] for r in ranks_table}) if backend == "nccl" else 1, wall / args.steps, phases,
+                                     "all_to_all_single over %s" % (dist.get_backend() if distributed else "one rank: identity"))
+        if not args.no_cpu_baseline:
+            base = single_transform_cpu_baseline(log_n)
     if rank == 0:
         print(json.dumps({
             "exchange_verified": verified, "ranks": ranks_table,
@@ -209,7 +274,7 @@ def bench_fourstep(args, dev, rank, world, distributed):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"forward+inverse {'slab-form' if slab else '4-step'} NTT n=2^{log_n} (n1=2^{l1} x n2=2^{l2}) over {world} GPU(s), one all_to_all_single per transform",
                        "log_n": log_n, "parallelism": f"column/row split x{world}, RCCL all-to-all"},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "cpu_baseline": base,
         }))
     if distributed:
         dist.barrier()
@@ -301,7 +366,9 @@ def bench_slab_single_process(args):
         "config": {"workload": f"forward+inverse slab-form NTT n=2^{log_n} (M1=2^{l1} x S1=2^{ls}) over {lanes} lane(s) on device(s) {sorted(set(devices))}, "
                                f"single process, exchange by {'RCCL grouped send/recv' if args.exchange == 'rccl' else 'hipMemcpyPeerAsync'}",
                    "log_n": log_n, "parallelism": f"column/row split x{lanes}, one exchange"},
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": multi_device_roofline(log_n, lanes, len(set(devices)), wall / args.steps, None,
+                                          "RCCL grouped send/recv" if args.exchange == "rccl" else "hipMemcpyPeerAsync, one copy stream per source"),
+        "cpu_baseline": None if args.no_cpu_baseline else single_transform_cpu_baseline(log_n)}))
 
 
 def shard_batch(total, world, rank, scaling):
@@ -669,6 +736,34 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / reps * 1e-3
 
+        def verify_fold_samples(evals_t, out_t, m, beta, x0=None, xs_t=None, nsamp=1 << 17):
+            """Outside every timed region: `nsamp` random outputs of a fold that was just timed (plus the first and last 64 and the
+            neighbourhood of every 2^20-th quad) against the oracle's fri_fold (src/math/fri.rs:27-48) on the gathered pairs.  Points:
+            x0 * w_m^i (structured) or xs_t[i] (explicit)."""
+            import oracle
+            half = m // 2
+            rs = np.random.default_rng(0xF01D)
+            seams = np.arange(0, half, 1 << 22)
+            idx = np.unique(np.concatenate([rs.integers(0, half, nsamp), np.arange(64), half - 1 - np.arange(64),
+                                            (seams[:, None] + np.arange(-4, 4)[None, :]).ravel() % half]))
+            it = torch.from_numpy(idx).to(dev)
+            u32 = lambda t: t.cpu().numpy().view(np.uint32).astype(np.uint64)
+            a, b, got = u32(evals_t[it]), u32(evals_t[it + half]), u32(out_t[it])
+            if xs_t is not None:
+                xs = u32(xs_t[it])
+            else:   # x0 * w_m^i by square-and-multiply over the index bits (vectorised; spot-checked against the oracle's pow below)
+                w = oracle.root_of_unity(m.bit_length() - 1)
+                xs = np.full(idx.size, x0, dtype=np.uint64)
+                for bit in range(m.bit_length()):
+                    sel = ((idx >> bit) & 1).astype(bool)
+                    xs[sel] = (xs[sel] * np.uint64(w)) % np.uint64(P)
+                    w = oracle.bb_mul(w, w)
+                for j in (0, idx.size // 2, idx.size - 1):
+                    assert int(xs[j]) == oracle.bb_mul(x0, oracle.bb_pow(oracle.root_of_unity(m.bit_length() - 1), int(idx[j])))
+            want = oracle.fri_fold(np.concatenate([a, b]), xs, beta)
+            assert (got == want).all(), f"fold of a 2^{m.bit_length() - 1} layer differs from the oracle at outputs {idx[got != want][:8]}"
+            return int(idx.size)
+
         for ln in (20, 24):
             nn = 1 << ln
             time.sleep(1.0)   # a lone transform is timed on a chip that is not still shedding the heat of the batched run
@@ -702,6 +797,8 @@ def main():
                 o2 = torch.empty(1 << 26, dtype=torch.int32, device=dev)
                 t_fold = time_dev(lambda: toyni_amd.fri_fold_device(c27, big.data_ptr(), o2.data_ptr(), 1 << 27, 123456789, 7, stream=stream), 20)
                 extras["fri_fold_m2^27"] = {"us": t_fold * 1e6, "GBps": 6.0 * (1 << 27) / t_fold / 1e9, "frac_of_hbm_peak": 6.0 * (1 << 27) / t_fold / 1e9 / HBM_PEAK_GBPS}
+                # what was timed is what is checked: the output of the last timed launch, sampled against the oracle
+                fold_checked = verify_fold_samples(big, o2, 1 << 27, 123456789, x0=7)
                 # the same object the NTT has: the fold kernel against the HBM roofline, kernel duration from HIP events here and from the
                 # committed rocprofv3 run, HBM bytes from the committed FETCH_SIZE / WRITE_SIZE passes
                 fp = committed_fold_profile()
@@ -715,6 +812,9 @@ def main():
                     "traffic": fp["traffic"] if fp else None,
                     "traffic_source": stamp(f"profiles/{os.path.basename(fp['file'])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)", fp["file"]) if fp else None,
                     "rocprof_kernel_ms": fp["rocprof_avg_ms"] if fp else None, "rocprof_launches": fp["launches"] if fp else None,
+                    "verified": True, "verified_outputs": fold_checked,
+                    "verified_how": "outputs of the last timed launch, sampled (random + both ends + chunk seams), against the oracle's fri_fold on the gathered pairs; "
+                                    "every output of the same kernel at 2^26 / 2^27: tests/test_gpu_fold_large.py",
                 }
                 del big, o2
                 c27.destroy()
@@ -726,9 +826,10 @@ def main():
                 # prefix product, two for the back-substitution, the coefficient, the application): ~9 per output = 4.5 per input element,
                 # 5 VALU instructions each, plus the adds, against the 39.3 T lane-ops/s of that instruction class
                 xs_lane_ops = 4.5 * 5 + 8
+                xs_checked = verify_fold_samples(buf, o, nn, 123456789, xs_t=xs24)
                 extras["fri_fold_xs_m2^24"] = {
                     "us": t_xs * 1e6, "GBps": 8.0 * nn / t_xs / 1e9, "frac_of_hbm_peak": 8.0 * nn / t_xs / 1e9 / HBM_PEAK_GBPS,
-                    "elements_per_s": nn / t_xs, "bound": "valu",
+                    "elements_per_s": nn / t_xs, "bound": "valu", "verified": True, "verified_outputs": xs_checked,
                     "valu": {"lane_ops_per_input_element_estimate": xs_lane_ops, "achieved_Tops_estimate": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
                              "frac_estimate": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
                     "note": "toyni_fri_fold_xs_device on a 2^24 layer, explicit points resident in HBM; 8 B algorithmic per input element (4 evals + 2 xs "
@@ -835,6 +936,41 @@ def main():
                                            "note": "blowup 32, coset shift 7; first pass reads 1/32 of the rows and skips butterflies with a zero partner"}
         del coeffs, ext, ref
         c_lde.destroy()
+
+        # ---- fft_ext / ifft_ext (src/math/domain.rs:129-151: what the downstream zkvm calls, src/ext.rs:1-8): 64 Ext vectors of 2^20
+        #      elements, AoS ([n][4] words), device-resident, through the interleaved passes -- no de-interleave on either side
+        e_log, e_vecs = 20, 64
+        c_e = toyni_amd.NttContext(1 << e_log, device=dev.index)
+        xe = torch.randint(0, P, (e_vecs * 4 << e_log,), dtype=torch.int32, device=dev)   # 1 GiB
+        xe0 = xe.clone()
+        pe = xe.data_ptr()
+        t_ef = time_dev(lambda: c_e.run_device_ext_batch(pe, pe, e_vecs, False, shift=7, stream=stream), 10)
+        xe.copy_(xe0)
+        c_e.run_device_ext_batch(pe, pe, e_vecs, False, shift=7, stream=stream)
+        c_e.run_device_ext_batch(pe, pe, e_vecs, True, shift=7, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(xe, xe0), "Ext round trip changed the data"
+        # one vector's coordinate 0 against the oracle (the last vector: a wrong tile order anywhere in the batch shows there or in the round trip)
+        import oracle
+        c_e.run_device_ext_batch(pe, pe, e_vecs, False, shift=7, stream=stream)
+        torch.cuda.synchronize()
+        last_in = xe0.view(e_vecs, 1 << e_log, 4)[e_vecs - 1, :, 0].cpu().numpy().view(np.uint32).astype(np.uint64)
+        last_out = xe.view(e_vecs, 1 << e_log, 4)[e_vecs - 1, :, 0].cpu().numpy().view(np.uint32)
+        assert (last_out == oracle.domain_fft(last_in, 1 << e_log, 7)).all(), "Ext transform differs from the oracle"
+        t_ei = time_dev(lambda: c_e.run_device_ext_batch(pe, pe, e_vecs, True, shift=7, stream=stream), 10)
+        t_eb = time_dev(lambda: c_e.run_device(pe, pe, 4 * e_vecs, False, shift=7, stream=stream), 10)   # the same bytes as base transforms
+        ext_elems = e_vecs << e_log
+        alg_ext = 32.0 * ext_elems        # 16 B read + 16 B written per Ext element per transform (the 8 B per base element of SURVEY 8(d), x 4)
+        extras["ntt_ext_64x2^20"] = {
+            "forward_ms": t_ef * 1e3, "inverse_ms": t_ei * 1e3, "ext_elements_per_s": ext_elems / t_ef,
+            "base_transforms_same_bytes_ms": t_eb * 1e3, "overhead_vs_base": t_ef / t_eb - 1.0,
+            "roofline": {"bound": "hbm", "achieved": alg_ext / t_ef / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_ext / t_ef / 1e9 / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_call": alg_ext, "note": "whole transform (its two pass launches), 32 B per Ext element"},
+            "verified": True,
+            "note": "coset forward / inverse of 64 Ext vectors x 2^20 (AoS, 1 GiB) in ONE call; rounds 2-3 ran ext_split -> batch of 4 -> ext_join per vector "
+                    "(two extra sweeps): A/B in profiles/r04_ab_ext.txt"}
+        del xe, xe0
+        c_e.destroy()
 
         # ---- the transforms of one proof (BASELINE configs[2]: trace_len 2^16, blowup 32 -> lde 2^21), device-resident, single
         #      transforms back to back: interpolate (INTT 2^16), coset LDE 2^16 -> 2^21, the two coset INTTs of src/fibonacci.rs:145,151

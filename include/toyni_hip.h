@@ -127,18 +127,23 @@ int toyni_lde_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_o
 int toyni_lde_host(toyni_ntt_ctx* ctx, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift);
 
 /* Extension-field transforms, fft_ext / ifft_ext (src/math/domain.rs:129-151): n Ext elements = 4 words each (AoS,
- * #[repr(C)] Ext { c: [BabyBear; 4] }).  The transform is base-linear, so it is the four coordinate transforms -- issued
- * here as ONE batch of 4 behind ONE call (host form: one PCIe round trip; the de-interleave runs on the device).
- * shift = coset shift (1 = standard domain). */
+ * #[repr(C)] Ext { c: [BabyBear; 4] }).  The transform is base-linear, i.e. the base transform of every coordinate (the reference
+ * de-interleaves into four vectors, transforms each and re-interleaves, :140-151).  Here the AoS vector is transformed AS IT IS: the
+ * pass kernels have an interleaved form in which the four coordinates of an element are four neighbouring columns (first / middle
+ * passes) or four interleaved rows (last pass), so an Ext transform costs exactly the passes of the plan -- no de-interleave sweep
+ * on either side -- and `batch` vectors go through one launch sequence.  shift = coset shift (1 = standard domain).
+ * _batch_device: d_in == d_out allowed; batch * n * 4 words each. */
 int toyni_ntt_ext_host(toyni_ntt_ctx* ctx, uint64_t* h_data, uint64_t shift, int inverse);
 int toyni_ntt_ext_device(toyni_ntt_ctx* ctx, uint32_t* d_data, uint32_t shift, int inverse, void* stream);
+int toyni_ntt_ext_batch_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream);
 
-/* fft_ext of a coefficient vector shorter than the domain (src/math/domain.rs:134-151 pads every coordinate column): the four
- * coordinate columns as one batch-of-4 low-degree extension, padding implied.  Ext elements are 4 words each (AoS).
+/* fft_ext of a coefficient vector shorter than the domain (src/math/domain.rs:134-151 pads every coordinate column): the interleaved
+ * low-degree extension, padding implied (see toyni_lde_device).  Ext elements are 4 words each (AoS) on both sides.
  * host: ncoeffs <= n Ext coefficients (4 * ncoeffs u64) in, n Ext evaluations (4 * n u64) out, only the coefficients uploaded;
- * device: (n >> log_blowup) Ext coefficients (packed u32 AoS) in, n out, out of place. */
+ * device: `batch` vectors of (n >> log_blowup) Ext coefficients (packed u32 AoS) in, n Ext evaluations each out, out of place. */
 int toyni_lde_ext_host(toyni_ntt_ctx* ctx, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift);
 int toyni_lde_ext_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_out, unsigned log_blowup, uint32_t shift, void* stream);
+int toyni_lde_ext_batch_device(toyni_ntt_ctx* ctx, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream);
 
 /* Multi-GPU 4-step transform of one size-n vector (n = n1 * n2 over G ranks, one all-to-all): the twiddle between
  * the two local stages, d_data[r][k] *= w_n^(+-(row0 + r) * k) for r < rows, k < row_len (ctx of size n;
@@ -339,6 +344,10 @@ int toyni_stream_wait_event(void* stream, void* event);
 int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSynchronize(stream); with a context: also releases what that stream outgrew */
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 int toyni_set_device(int device);
+/* Diagnostics: the symbols (one per line) of every kernel this process has launched through the library so far.  Returns the bytes
+ * needed including the terminating 0; (NULL, 0) asks for the size.  With TOYNI_LAUNCH_LOG=<file> in the environment every newly seen
+ * symbol is also appended to that file.  Used by the test suite to prove that every kernel of the shipped binary was run. */
+size_t toyni_launched_kernels(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

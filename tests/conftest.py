@@ -11,6 +11,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Every kernel symbol the library launches during this session -- in this process and in every child process a test starts
+    # (measurement build, other dispatch knobs, compiled C++ hosts) -- is appended to this file by the library itself
+    # (TOYNI_LAUNCH_LOG, include/toyni_hip.h section 4); tests/test_zz_kernel_coverage.py reads it at the end of the session.
+    if "TOYNI_LAUNCH_LOG" not in os.environ:
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix="toyni_launch_log_", suffix=".txt")
+        os.close(fd)
+        os.environ["TOYNI_LAUNCH_LOG"] = path
+        config._toyni_launch_log_owned = path
+
+
+def pytest_unconfigure(config):
+    path = getattr(config, "_toyni_launch_log_owned", None)
+    if path and os.path.exists(path):
+        os.unlink(path)
 
 
 @pytest.fixture(scope="session")

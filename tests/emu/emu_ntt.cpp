@@ -61,6 +61,8 @@ static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
 static bool latency_plan = false;   // "Q1": n = 2^21 / 2^22 through their two-pass latency plan (2048-point three-step shapes)
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
+// LQ > 0: the interleaved (Ext, AoS) passes -- `batch` counts base-field transforms, 2^LQ of them interleaved word by word
+template <int LQ = 0>
 static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* work, uint32_t* dst, uint64_t batch, uint32_t shift = 1,
                           int lde_log = 0) {
     const std::vector<uint32_t>& blob = inverse ? plan.inv : plan.fwd;
@@ -74,7 +76,7 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         cs.hi = cblob.data() + hi_off;
     }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
-    if (use_lds && plan.lds_la && !lde_log) {      // n = 2^11 .. 2^15: the single-sweep kernel, phase by phase (two barriers)
+    if (LQ == 0 && use_lds && plan.lds_la && !lde_log) {      // n = 2^11 .. 2^15: the single-sweep kernel, phase by phase (two barriers)
         bool okl = lds_transform(plan, blob.data(), inverse, src, dst, batch, [&](auto pass, const LdsArgs& g, uint64_t ntiles) {
             using L = decltype(pass);
             std::vector<uint32_t> lds(L::LDS_WORDS, 0xDEADBEEFu);
@@ -95,7 +97,7 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         CHECK(okl, "lds transform rejected log_n=%d", plan.log_n);
         return;
     }
-    bool ok = for_each_pass(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
+    bool ok = for_each_pass<LQ>(plan, blob.data(), inverse, src, work, dst, batch, [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
         using P = decltype(pass);
         constexpr int LZ = decltype(lzc)::value;
         std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);  // exact size: an out-of-range LDS word is an ASan error
@@ -132,6 +134,42 @@ static void test_coset(int log_n, uint64_t batch, uint32_t shift) {
     bad = 0;
     for (size_t i = 0; i < n * batch; ++i) if (buf[i] != (uint32_t)want[i]) ++bad;
     CHECK(bad == 0, "coset ifft log_n=%d batch=%llu: %zu mismatches", log_n, (unsigned long long)batch, bad);
+}
+
+// fft_ext / ifft_ext (src/math/domain.rs:129-151): `vectors` Ext vectors of n elements in the reference's AoS layout ([n][4]); the
+// interleaved passes must give, coordinate by coordinate, the oracle's base transforms.  lde_log > 0: the forward transform of a
+// compact coefficient vector ([n >> lde_log][4]) with the padding implied.
+static void test_ext(int log_n, uint64_t vectors, uint32_t shift, int lde_log = 0) {
+    NttPlan plan;
+    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    const size_t n = (size_t)1 << log_n, n_in = n >> lde_log;
+    std::vector<uint64_t> ref(4 * n_in * vectors);
+    orc_fill_splitmix(ref.data(), ref.size(), 0xE7700ull + (uint64_t)log_n * 131 + (uint64_t)lde_log);
+    std::vector<uint32_t> in(ref.size()), work(4 * n * vectors, 0xABABABABu), out(4 * n * vectors, 0xCDCDCDCDu);
+    for (size_t i = 0; i < ref.size(); ++i) in[i] = (uint32_t)ref[i];
+    std::vector<uint64_t> col(n_in), want(n);
+    // forward (coset shift fused, padding implied), out of place
+    emu_transform<2>(plan, false, in.data(), work.data(), out.data(), 4 * vectors, shift, lde_log);
+    size_t bad = 0;
+    for (uint64_t v = 0; v < vectors; ++v)
+        for (int k = 0; k < 4; ++k) {
+            for (size_t j = 0; j < n_in; ++j) col[j] = ref[(v * n_in + j) * 4 + k];
+            orc_domain_fft(want.data(), n, col.data(), n_in, shift);
+            for (size_t j = 0; j < n; ++j) bad += out[(v * n + j) * 4 + k] != (uint32_t)want[j];
+        }
+    CHECK(bad == 0, "ext forward log_n=%d vectors=%llu shift=%u lde_log=%d: %zu mismatches", log_n, (unsigned long long)vectors, shift, lde_log, bad);
+    if (lde_log) return;
+    // inverse of the same data (as evaluations), in place
+    std::vector<uint32_t> buf = in;
+    emu_transform<2>(plan, true, buf.data(), work.data(), buf.data(), 4 * vectors, shift);
+    bad = 0;
+    for (uint64_t v = 0; v < vectors; ++v)
+        for (int k = 0; k < 4; ++k) {
+            for (size_t j = 0; j < n; ++j) want[j] = ref[(v * n + j) * 4 + k];
+            orc_domain_ifft(want.data(), n, shift);
+            for (size_t j = 0; j < n; ++j) bad += buf[(v * n + j) * 4 + k] != (uint32_t)want[j];
+        }
+    CHECK(bad == 0, "ext inverse log_n=%d vectors=%llu shift=%u: %zu mismatches", log_n, (unsigned long long)vectors, shift, bad);
 }
 
 static void test_field() {
@@ -582,6 +620,15 @@ int main(int argc, char** argv) {
             build_plan(log_n, probe);
             for (int z = 1; z <= probe.pass[0].log_m; ++z) test_lde(log_n, z == 1 ? 3 : 1, z, z & 1 ? 7u : 1u);
         }
+        if (log_n >= 1) {                           // Ext (AoS) transforms: one vector, a ragged few, plain and coset
+            test_ext(log_n, 1, 1);
+            test_ext(log_n, log_n <= 10 ? 11 : 2, 7);
+            if (log_n >= 11) {
+                NttPlan probe;
+                build_plan(log_n, probe);
+                for (int z = 1; z <= probe.pass[0].log_m; z += 2) test_ext(log_n, 1, 7, z);
+            }
+        }
         std::printf("log_n=%d failures=%d\n", log_n, failures);
         std::fflush(stdout);
     }
@@ -602,6 +649,16 @@ int main(int argc, char** argv) {
         if (argv[i][0] == 'l') {                    // "lLOGxZ": low-degree extension of 2^(LOG-Z) coefficients to 2^LOG points
             test_lde(std::atoi(argv[i] + 1), 2, xb ? std::atoi(xb + 1) : 5, 7);
             std::printf("lde %s failures=%d\n", argv[i], failures);
+            std::fflush(stdout);
+            continue;
+        }
+        if (argv[i][0] == 'e') {                    // "eLOGxV": V Ext vectors of 2^LOG elements (AoS), plain + coset + LDE by 32 / 4
+            const int lg = std::atoi(argv[i] + 1);
+            const uint64_t vecs = xb ? (uint64_t)std::atoll(xb + 1) : 1;
+            test_ext(lg, vecs, 1);
+            test_ext(lg, vecs, 1234567891u);
+            if (lg >= 11) { test_ext(lg, vecs, 7, 5); test_ext(lg, vecs, 7, 2); }
+            std::printf("ext %s failures=%d\n", argv[i], failures);
             std::fflush(stdout);
             continue;
         }

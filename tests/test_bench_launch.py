@@ -73,6 +73,11 @@ def test_two_ranks_on_one_gpu_rehearsal():
         assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
         if "--workload" in extra:    # the forward half was gathered and compared with the single-device transform
             assert out["exchange_verified"] is True
+            # the one-transform lines carry a roofline object (HBM + exchange, per-phase times from events)
+            roof = out["roofline"]
+            assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["algorithmic_bytes_per_step"] == 16 * (1 << int(extra[-1]))
+            assert roof["phases_ms_per_step"]["exchange"] > 0 and roof["exchange"]["bytes_sent_per_rank_per_transform"] > 0
+            assert ("slab_pass" in roof["phases_ms_per_step"]) == (extra[1] == "slab")
         if "--batch" in extra:       # the per-rank table: which device every rank used and its own step time
             assert [r["rank"] for r in out["ranks"]] == [0, 1] and all(r["ms_per_step"] > 0 and r["transforms_per_step"] == 16 for r in out["ranks"])
             assert "rank  device  pci" in res.stderr
@@ -82,3 +87,19 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = _last_json(res.stdout)
     assert out["scaling"] == "strong" and [r["transforms_per_step"] for r in out["ranks"]] == [10, 8] and out["config"]["batch_total"] == 9
+
+
+@pytest.mark.gpu
+def test_single_process_slab_line_carries_roofline_and_baseline():
+    """The configs[4] line as an 8-GPU node would print it, rehearsed with 8 lanes on the one device: `roofline` (algorithmic bytes vs
+    the HBM of the devices in use, exchange bytes vs the xGMI links) and `cpu_baseline` (the oracle at n, or extrapolated and labelled)."""
+    env = dict(os.environ, TOYNI_BENCH_LANES_ON_ONE_DEVICE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "slab-sp", "--gpus", "8", "--log-n", "25", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = _last_json(res.stdout)
+    assert out["exchange_verified"] is True and out["lanes"] == 8
+    roof, base = out["roofline"], out["cpu_baseline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert roof["exchange"]["bytes_sent_per_rank_per_transform"] == 4 * (1 << 25) / 8 * 7 / 8 and "ONE device" in roof["exchange"]["note"]
+    assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and base["extrapolated"] is True and "EXTRAPOLATED" in base["sample"]

@@ -864,7 +864,7 @@ def test_fold_ext_embeds_base_fold(ta):
         ta.fri_fold_ext(np.zeros((3, 4), dtype=np.uint64), np.ones(3, dtype=np.uint64), [1, 0, 0, 0])
 
 
-@pytest.mark.parametrize("log_n,shift", [(3, 1), (10, 7), (16, 7)])
+@pytest.mark.parametrize("log_n,shift", [(0, 1), (1, 7), (3, 1), (5, 7), (7, 1), (10, 7), (11, 1), (13, 7), (16, 7), (19, 3), (20, 7), (21, 1)])
 def test_ext_transform_single_call(ta, log_n, shift):
     # fft_ext / ifft_ext (src/math/domain.rs:129-151) as one device call: equals four base transforms of the coordinates
     n = 1 << log_n
@@ -883,6 +883,60 @@ def test_ext_transform_single_call(ta, log_n, shift):
     ctx.synchronize()
     assert (buf.download(np.uint32, 4 * n).reshape(n, 4) == evals).all()
     buf.free()
+
+
+@pytest.mark.parametrize("log_n,batch,shift", [(2, 9, 1), (6, 33, 7), (10, 5, 7), (10, 64, 1), (12, 7, 7), (14, 40, 1), (16, 9, 7), (18, 16, 5), (20, 3, 7), (20, 16, 1)])
+def test_ext_batched_device_resident_vs_oracle(ta, log_n, batch, shift):
+    # `batch` Ext vectors ([batch][n][4] packed u32) through toyni_ntt_ext_batch_device: every coordinate of every vector is the
+    # oracle's coset transform of that coordinate column; out of place forward, in place inverse
+    n = 1 << log_n
+    rng = np.random.default_rng(1000 * log_n + batch)
+    x = rng.integers(0, P, size=(batch, n, 4), dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, b = DevBuf(ta, x.nbytes), DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device_ext_batch(a.ptr, b.ptr, batch, False, shift=shift)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size).reshape(batch, n, 4)
+        assert (a.download(np.uint32, x.size).reshape(x.shape) == x).all(), "out-of-place transform modified its input"
+        for v in range(batch):
+            for k in range(4):
+                assert (y[v, :, k] == oracle.domain_fft(x[v, :, k].astype(np.uint64), n, shift)).all(), (v, k)
+        ctx.run_device_ext_batch(b.ptr, b.ptr, batch, True, shift=shift)
+        ctx.synchronize()
+        assert (b.download(np.uint32, x.size).reshape(x.shape) == x).all()
+    finally:
+        a.free(); b.free()
+
+
+def test_ext_transform_launches_exactly_the_plans_passes(ta):
+    # no de-interleave sweep on either side -- an Ext transform is the plan's passes and nothing else
+    code = """
+import numpy as np, ctypes
+import toyni_amd
+from toyni_amd import _lib
+from test_gpu_parity import DevBuf
+for log_n, batch in ((10, 3), (16, 1), (20, 2), (21, 1)):
+    n = 1 << log_n
+    ctx = toyni_amd.ntt.get_or_create_ctx(n)
+    buf = DevBuf(toyni_amd, 16 * n * batch)
+    buf.upload(np.arange(4 * n * batch, dtype=np.uint32) % 2013265921)
+    ctx.run_device_ext_batch(buf.ptr, buf.ptr, batch, False, shift=7)   # warm: tables, scratch
+    ctx.synchronize()
+    before = set(_lib.launched_kernels())
+    ctx.timing(True)
+    ctx.run_device_ext_batch(buf.ptr, buf.ptr, batch, False, shift=7)
+    ctx.run_device_ext_batch(buf.ptr, buf.ptr, batch, True, shift=7)
+    t = ctx.read_timing()
+    ctx.timing(False)
+    assert t["launches"]["forward"] == [1] * ctx.passes and t["launches"]["inverse"] == [1] * ctx.passes, (log_n, t)
+    assert set(_lib.launched_kernels()) == before, "an Ext transform launched something besides its passes"
+    buf.free()
+print("EXT LAUNCHES OK")
+"""
+    res = _run_on_measurement_build(code)
+    assert res.returncode == 0 and "EXT LAUNCHES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
 def test_single_process_multi_gpu_batch_runner(ta):

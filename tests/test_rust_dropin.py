@@ -43,13 +43,90 @@ def test_build_rs_tracks_every_copied_file():
             assert f in listed, f"toyni_amd/csrc/{f} is missing from INTEGRATION.md section 1 (the crate's hip/ directory would not build)"
 
 
+REFERENCE = "/root/reference"   # present in the build container only (never on the GPU box)
+
+
+def _load_apply():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("toyni_rust_apply", os.path.join(ROOT, "rust", "apply.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _patched_checkout(tmp_path):
+    """A temporary copy of the reference checkout with rust/apply.py applied (build container only)."""
+    dst = tmp_path / "toyni_checkout"
+    shutil.copytree(REFERENCE, dst, ignore=shutil.ignore_patterns(".git", "target"))
+    for d, _, names in os.walk(dst):
+        os.chmod(d, 0o755)
+        for n in names:
+            os.chmod(os.path.join(d, n), 0o644)
+    return dst, _load_apply().apply(str(dst))
+
+
+def test_apply_script_lists_the_files_of_integration_md():
+    assert sorted(_load_apply().HIP_SOURCES + ["toyni_hip.h"]) == sorted(os.path.basename(f) for f in _integration_file_list())
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference checkout (build container only)")
+def test_apply_script_patches_a_reference_checkout_mechanically(tmp_path):
+    """the drop-in as a program.  rust/apply.py on a copy of the reference: the CPU half of src/ntt.rs is untouched, the
+    `mod cuda` block is gone, exactly one real and one stub module took its place, the reference's public names are exported, the
+    call sites of src/math/domain.rs still resolve, the GPU tests nested in the old block were carried over, the feature table and
+    the build script are the new ones, cuda/ is gone and hip/ holds the library."""
+    dst, report = _patched_checkout(tmp_path)
+    ref_ntt = open(os.path.join(REFERENCE, "src", "ntt.rs")).read()
+    new_ntt = open(dst / "src" / "ntt.rs").read()
+    a, b = report["ntt_rs_block_lines"]
+    ref_lines, new_lines = ref_ntt.splitlines(keepends=True), new_ntt.splitlines(keepends=True)
+    assert 80 <= a <= 90 and 300 <= b <= 330, (a, b)                      # SURVEY.md 8(a): the GPU wrapper is src/ntt.rs:83-315
+    assert ref_lines[:a - 1] == new_lines[:a - 1], "the CPU transform above the GPU block must stay byte for byte"
+    assert "".join(ref_lines[b:]) == new_ntt[-len("".join(ref_lines[b:])):], "the CPU tests below the GPU block must stay byte for byte"
+    assert not re.search(r"^\s*mod cuda\b", new_ntt, flags=re.M) and 'name = "ntt_cuda"' not in new_ntt and "pub use cuda::" not in new_ntt
+    assert len(re.findall(r"^mod gpu \{", new_ntt, flags=re.M)) == 1 and len(re.findall(r"^mod gpu_absent \{", new_ntt, flags=re.M)) == 1
+    for cfg in ('#[cfg(all(feature = "hip", has_hip))]', '#[cfg(all(feature = "hip", not(has_hip)))]'):
+        # the four public aliases of the reference (src/ntt.rs:314-315), under both cfgs
+        stmt = next(l for l in new_ntt.split(cfg)[1:] if re.match(r"\s*pub use [^;]*as cuda_available", l))
+        for alias in ("as cuda_available", "as intt_cuda", "as ntt_cuda", "as CudaBuffer"):
+            assert alias in stmt.split(";")[0], (cfg, alias)
+    # every crate::ntt:: name the callers use (src/math/domain.rs:90-97,113-119) is still exported
+    dom = open(dst / "src" / "math" / "domain.rs").read()
+    assert dom == open(os.path.join(REFERENCE, "src", "math", "domain.rs")).read(), "the call sites are not edited"
+    used = set(re.findall(r"crate::ntt::(\w+)", dom))
+    assert used >= {"cuda_available", "ntt_cuda", "intt_cuda"}
+    for name in used:
+        assert re.search(rf"pub use [^;]*\b(?:as )?{name}\b", new_ntt), f"crate::ntt::{name} no longer resolves"
+    # the reference's three GPU tests (nested in the old block, src/ntt.rs:253-311) were carried over from the checkout into `mod gpu`
+    assert report["carried_test_lines"] >= 40
+    gpu_mod = new_ntt[new_ntt.index("mod gpu {"):new_ntt.index("mod gpu_absent {")]
+    for t in ("fn test_cuda_available", "fn test_cuda_ntt_vs_cpu", "fn test_cuda_intt_roundtrip"):
+        assert t in gpu_mod and t in ref_ntt, t
+    assert "use self::{gpu_available as cuda_available" in gpu_mod
+    assert new_ntt.count("{") == new_ntt.count("}")
+    # Cargo.toml: one [features] table, the new one; everything else as before
+    cargo, ref_cargo = open(dst / "Cargo.toml").read(), open(os.path.join(REFERENCE, "Cargo.toml")).read()
+    assert cargo.count("[features]") == 1 and 'hip = []' in cargo and 'cuda = ["hip"]' in cargo and "cuda = []" not in cargo
+    strip = lambda t: re.sub(r"^\[features\]\n(?:(?!\[)[^\n]*\n)*", "", t, flags=re.M).split()
+    assert strip(cargo) == strip(ref_cargo)
+    assert open(dst / "build.rs").read() == open(os.path.join(ROOT, "rust", "build.rs")).read()
+    assert not (dst / "cuda").exists() and sorted(os.listdir(dst / "hip")) == sorted(os.path.basename(f) for f in _integration_file_list())
+    # applying twice is refused, not silently doubled
+    with pytest.raises(SystemExit):
+        _load_apply().apply(str(dst))
+
+
 def test_following_integration_md_produces_a_linkable_archive(tmp_path):
     import __graft_entry__ as entry
-    crate = tmp_path / "toyni"
-    (crate / "hip").mkdir(parents=True)
-    for f in _integration_file_list():
-        assert os.path.exists(f), f"INTEGRATION.md lists {f}, which does not exist"
-        shutil.copy(f, crate / "hip")
+    if os.path.isdir(REFERENCE):
+        # build container: the crate IS a patched copy of the reference (rust/apply.py), so build.rs's commands run in the real layout
+        crate, _ = _patched_checkout(tmp_path)
+    else:
+        crate = tmp_path / "toyni"
+        (crate / "hip").mkdir(parents=True)
+        for f in _integration_file_list():
+            assert os.path.exists(f), f"INTEGRATION.md lists {f}, which does not exist"
+            shutil.copy(f, crate / "hip")
     # every csrc file the translation unit includes must be on the list (a file missing from INTEGRATION.md breaks the crate)
     out = tmp_path / "out"
     out.mkdir()

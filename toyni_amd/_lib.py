@@ -82,6 +82,8 @@ SIGNATURES = {
     "toyni_lde_ext_device": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_ntt_ext_host": (c_int, [c_void_p, c_void_p, c_u64, c_int]),
     "toyni_ntt_ext_device": (c_int, [c_void_p, c_void_p, c_u32, c_int, c_void_p]),
+    "toyni_ntt_ext_batch_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_u32, c_int, c_void_p]),
+    "toyni_lde_ext_batch_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, ctypes.c_uint, c_u32, c_void_p]),
     "toyni_fourstep_twiddle_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_ctx_first_pass_points": (c_size, [c_void_p]),
     "toyni_first_pass_points": (c_size, [c_u32]),
@@ -134,6 +136,7 @@ SIGNATURES = {
     "toyni_stream_synchronize": (c_int, [c_void_p, c_void_p]),
     "toyni_ntt_ctx_trim": (c_int, [c_void_p]),
     "toyni_set_device": (c_int, [c_int]),
+    "toyni_launched_kernels": (c_size, [ctypes.c_char_p, c_size]),
 }
 
 # include/toyni_hip_tools.h: present only in the measurement build libtoyni_hip_tools.so (TOYNI_LIB_OVERRIDE points at it)
@@ -172,3 +175,11 @@ class ToyniError(RuntimeError):
 def check(status: int, what: str) -> None:
     if status != 0:
         raise ToyniError(what, status)
+
+
+def launched_kernels():
+    """Symbols of the kernels this process has launched through the library so far (diagnostics; toyni_launched_kernels)."""
+    need = lib.toyni_launched_kernels(None, 0)
+    buf = ctypes.create_string_buffer(need + 4096)
+    lib.toyni_launched_kernels(buf, len(buf))
+    return [s for s in buf.value.decode().split("\n") if s]

@@ -146,9 +146,19 @@ constexpr uint32_t cx_bitrev(uint32_t x, int bits) {
     return r;
 }
 
-template <int KIND, int LE1, int LE2, int LC, bool NT_ = false>
+// LQ_ > 0 (round 4): Q = 2^LQ_ independent transforms INTERLEAVED word by word -- element j of transform q sits at word
+// (j << LQ) + q -- which is the AoS layout of an Ext vector (4 x u32 per element, src/ext.rs / src/math/domain.rs:129-151: an
+// Ext transform is the base transform of each coordinate).  A column pass sees such data as Q times as many columns whose twiddle
+// column is (column >> LQ) (the host passes log_S / in_prefix_log inflated by LQ); the row kinds run C "virtual rows"
+// c = (row << LQ) | q per tile, lanes running over (q, position) so that loads and stores stay contiguous, and park virtual row c
+// in LDS row rho(c) (coordinate-major within blocks of 8 rows: conflict-free for both the step-1 writes and the step-2 reads).
+template <int KIND, int LE1, int LE2, int LC, bool NT_ = false, int LQ_ = 0>
 struct Pass {
     static_assert(LE2 <= LE1 && LE1 <= 5 && LE1 >= 1, "step sizes");
+    static constexpr int LQ = LQ_;
+    static constexpr uint32_t Q = 1u << LQ_;
+    static_assert(LQ_ == 0 || LQ_ == 2, "interleave: none, or the four coordinates of an Ext element");
+    static_assert(LQ_ == 0 || KIND == KIND_COL || LC - LQ_ >= (KIND == KIND_ROW_T ? 2 : 3) || LE2 == 0, "interleaved rows: 4 or >= 8 rows per coordinate");
     static constexpr int LM = LE1 + LE2;
     static constexpr int LE1_ = LE1;
     static constexpr int STEPS = LE2 > 0 ? 2 : 1;
@@ -173,7 +183,7 @@ struct Pass {
     static constexpr uint32_t row_pitch() {
         uint32_t base = E1 * (E2 + 1);
         // residue of PITCH mod 32 that spreads the tile rows a 32-lane group touches in step 2
-        uint32_t want = KIND == KIND_ROW_T ? (C <= 16 ? 2u : 1u) : (E1 < 32 ? E1 : 0u);
+        uint32_t want = KIND == KIND_ROW_T ? (C <= 16 ? 2u : 1u) : (LQ_ > 0 ? 1u : (E1 < 32 ? E1 : 0u));
         return base + ((want + 32u - (base & 31u)) & 31u);
     }
     static constexpr uint32_t PITCH = row_pitch();
@@ -191,7 +201,16 @@ struct Pass {
     }
     static constexpr uint32_t MIN_WAVES = min_waves_per_simd();
 
-    static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t hi, uint32_t low) { return c * C_STRIDE + hi * HI_STRIDE + low * LOW_STRIDE; }
+    // LDS row of virtual row c = (cc << LQ) | q of an interleaved row tile.  >= 8 rows per coordinate: 8 q + (cc & 7) + 32 (cc >> 3)
+    // with PITCH = 1 mod 32 -- a step-1 wave (lanes over q and eight consecutive positions) hits banks 8 q + position, a step-2
+    // group of 32 consecutive virtual rows 32 different rows mod 32; 4 rows per coordinate (16-row tiles): 4 q + cc, PITCH = 2 mod 32.
+    static TOYNI_HD uint32_t lds_row(uint32_t c) {
+        if (LQ_ == 0 || KIND == KIND_COL) return c;
+        const uint32_t q = c & (Q - 1u), cc = c >> LQ_;
+        if ((C >> LQ_) >= 8u) return (q << 3) + (cc & 7u) + ((cc >> 3) << 5);
+        return q * (C >> LQ_) + cc;
+    }
+    static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t hi, uint32_t low) { return lds_row(c) * C_STRIDE + hi * HI_STRIDE + low * LOW_STRIDE; }
 
     // ---- tiles -----------------------------------------------------------------------------------------
     // A tile is addressed as (uniform 64-bit base pointer) + (32-bit per-thread BYTE offset): every offset inside a
@@ -229,16 +248,17 @@ struct Pass {
             t.out = a.out + base;
             t.col0 += a.col_base;  // from here on col0 only feeds twiddle exponents
         } else if (KIND == KIND_ROW_T) {
+            // interleaved: a tile's C virtual rows are C >> LQ consecutive k_1 times the Q transforms; b counts Q-groups
             const uint32_t mid = bid & ((1u << a.log_mid) - 1);
-            const uint32_t k1_tiles_log = a.log_M1 - LC;
-            const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << LC;
+            const uint32_t k1_tiles_log = a.log_M1 - (LC - LQ_);
+            const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << (LC - LQ_);
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
             t.row_shift = a.log_n - a.log_M1;
-            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM));
-            t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
+            t.in = a.in + (((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM)) << LQ_);
+            t.out = a.out + (((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
             t.out0 = k1_0 + (mid << a.log_M1);
         } else {
-            const uint64_t row0 = (uint64_t)bid << LC;
+            const uint64_t row0 = (uint64_t)bid << LC;   // virtual rows (interleaved: Q per batch entry; C is a multiple of Q)
             t.in = a.in + (row0 << LM);
             t.out = a.out + (row0 << LM);
             const uint64_t left = a.rows_total - row0;
@@ -248,28 +268,34 @@ struct Pass {
     }
 
     // element offset of tile element (c, r) in the input (linear in c and r)
+    // (interleaved row kinds: linear in r / k only, which is all the callers use -- c = (row << LQ) | q)
     static TOYNI_HD uint32_t in_offset(const PassArgs& a, const Tile& t, uint32_t c, uint32_t r) {
         if (KIND == KIND_COL) return (r << a.log_S) + c;
-        if (KIND == KIND_ROW_T) return (c << t.row_shift) + r;
-        return (c << LM) + r;
+        if (KIND == KIND_ROW_T) return ((((c >> LQ_) << t.row_shift) + r) << LQ_) + (c & (Q - 1u));
+        return ((((c >> LQ_) << LM) + r) << LQ_) + (c & (Q - 1u));
     }
     // element offset of finished element (c, natural sub-index k) in the output (linear in c and k)
     static TOYNI_HD uint32_t out_offset(const PassArgs& a, uint32_t c, uint32_t k) {
         if (KIND == KIND_COL) return (k << a.log_S) + c;
-        if (KIND == KIND_ROW_T) return c + (k << (a.log_n - LM));
-        return (c << LM) + k;
+        if (KIND == KIND_ROW_T) return c + (k << (a.log_n - LM + LQ_));
+        return ((((c >> LQ_) << LM) + k) << LQ_) + (c & (Q - 1u));
     }
 
     // ---- thread coordinates ----------------------------------------------------------------------------
     // step 1: KIND_COL lanes run over columns first (64-byte row segments), KIND_ROW_* over the contiguous row
+    // (interleaved row kinds: the Q transforms of one position are the fastest lanes -- consecutive words in memory)
     static TOYNI_HD void coords1(uint32_t tid, uint32_t& c, uint32_t& lo) {
         if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
-        else { lo = tid & (E2 - 1); c = tid >> LE2; }
+        else if (LQ_ == 0) { lo = tid & (E2 - 1); c = tid >> LE2; }
+        else { lo = (tid >> LQ_) & (E2 - 1); c = ((tid >> (LQ_ + LE2)) << LQ_) | (tid & (Q - 1u)); }
     }
     // step 2, group g of the thread: lanes run over what is contiguous in the OUTPUT
     static TOYNI_HD void coords2(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& hi) {
         const uint32_t gamma = tid + g * T;
-        if (KIND == KIND_ROW_N) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
+        if (KIND == KIND_ROW_N) {
+            if (LQ_ == 0) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
+            else { hi = (gamma >> LQ_) & (E1 - 1); c = ((gamma >> (LQ_ + LE1)) << LQ_) | (gamma & (Q - 1u)); }
+        }
         else { c = gamma & (C - 1); hi = gamma >> LC; }
     }
 
@@ -283,7 +309,7 @@ struct Pass {
     static TOYNI_HD TwiddleRaw group_twiddle_issue(const PassArgs& a, const Tile& t, uint32_t c, uint32_t khi) {
         TwiddleRaw r{0u, 0u, 0u, 0u};
         if (KIND == KIND_COL) {
-            const uint32_t jcol = t.col0 + c;
+            const uint32_t jcol = (t.col0 + c) >> LQ_;          // interleaved: Q consecutive columns share a twiddle column
             const uint32_t mask = (1u << a.tw_lowbits) - 1u;
             const uint32_t ea = jcol * khi, eg = jcol << LSH;   // < L <= 2^27
             r.a_lo = a.tw_lo[ea & mask];
@@ -292,7 +318,7 @@ struct Pass {
             r.g_hi = a.tw_hi[eg >> a.tw_lowbits];
         } else if (a.cs_mode == 2u) {
             // output coset factor s^k of the group's first element (b = 0): the in-transform output index
-            const uint32_t e0 = KIND == KIND_ROW_T ? t.out0 + c + (khi << (a.log_n - LM)) : khi;
+            const uint32_t e0 = KIND == KIND_ROW_T ? t.out0 + (c >> LQ_) + (khi << (a.log_n - LM)) : khi;
             r.a_lo = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
             r.a_hi = a.cs_hi[e0 >> a.cs_lowbits];
         }
@@ -351,7 +377,7 @@ struct Pass {
         } else {
             const bool scaled = KIND == KIND_ROW_N && a.scale != 0u;  // 1-pass inverse only (multi-pass: the first pass scales)
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (!TWO_STEP && KIND == KIND_ROW_N && !NT_ && NB >= 4) {   // the thread's whole row, consecutive words: 16-byte stores
+            if constexpr (!TWO_STEP && KIND == KIND_ROW_N && !NT_ && NB >= 4 && LQ_ == 0) {   // the thread's whole row, consecutive words: 16-byte stores
 #pragma unroll
                 for (uint32_t q = 0; q < NB / 4; ++q) {
                     uint32_t v[4];
@@ -612,7 +638,7 @@ struct Pass {
 #if defined(__HIP_DEVICE_COMPILE__)
             // one thread per row (single-step shapes): its E1 words are consecutive -- four per load instead of one (a wave's scalar
             // loads each touch 32 different lines; measured at 2^28 elements: n = 2^4 2.9 -> see profiles/r02_sweep.txt)
-            if constexpr (!TWO_STEP && KIND != KIND_COL && !NT_ && LZ == 0 && I0 == 0 && I1 == E1 && E1 >= 4) {
+            if constexpr (!TWO_STEP && KIND != KIND_COL && !NT_ && LZ == 0 && I0 == 0 && I1 == E1 && E1 >= 4 && LQ_ == 0) {
 #pragma unroll
                 for (uint32_t q = 0; q < E1 / 4; ++q) {
                     const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(base + off0 + 16u * q);
@@ -646,7 +672,7 @@ struct Pass {
         if (KIND != KIND_ROW_T && a.cs_mode == 1u) {
             uint32_t c, lo;
             coords1(tid, c, lo);
-            const uint32_t j0 = KIND == KIND_COL ? (lo << a.log_S) + t.col0 + c : lo;  // in-transform index of register 0
+            const uint32_t j0 = KIND == KIND_COL ? ((lo << a.log_S) + t.col0 + c) >> LQ_ : lo;  // in-transform index of register 0
             r.lo = a.cs_lo[j0 & ((1u << a.cs_lowbits) - 1u)];
             r.hi = a.cs_hi[j0 >> a.cs_lowbits];
         }

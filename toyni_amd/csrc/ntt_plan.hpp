@@ -218,13 +218,15 @@ inline int& wide_min_log_tiles32() {
     return v;
 }
 
-template <class F>
+// LQ > 0: the interleaved (Ext, AoS) variants -- two-step and single-step shapes only (a lone Ext transform is four transforms' worth
+// of tiles, the three-step latency shapes are not instantiated for it), tiles of at least 16 virtual rows / columns.
+template <int LQ = 0, class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
     // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
-    if (log_m == 11 || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m))) {
-#define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false>{}); return true; }
+    if (LQ == 0 && (log_m == 11 || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)))) {
+#define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { if constexpr (LQ == 0) f(Pass3<K, A, B, D, 2, false>{}); return true; }
         TOYNI_PASS3_CASE(KIND_COL, 4, 4, 3)
         TOYNI_PASS3_CASE(KIND_ROW_T, 4, 4, 3)
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 2)
@@ -235,14 +237,14 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
         TOYNI_PASS3_CASE(KIND_ROW_T, 4, 3, 3)
 #undef TOYNI_PASS3_CASE
     }
-#define TOYNI_PASS_GO(K, A, B, LC_) do { if (nt) f(Pass<K, A, B, LC_, true>{}); else f(Pass<K, A, B, LC_, false>{}); } while (0)
+#define TOYNI_PASS_GO(K, A, B, LC_) do { if (nt) f(Pass<K, A, B, LC_, true, LQ>{}); else f(Pass<K, A, B, LC_, false, LQ>{}); } while (0)
 #define TOYNI_PASS_CASE(K, A, B, LC_) \
     if (kind == K && log_m == (A) + (B)) { TOYNI_PASS_GO(K, A, B, LC_); return true; }
 #define TOYNI_PASS_CASE_W(K, A, B)                                                    \
     if (kind == K && log_m == (A) + (B)) {                                             \
         if (log_tiles32 >= 9) TOYNI_PASS_GO(K, A, B, 5);                               \
-        else if (log_tiles32 >= 7) TOYNI_PASS_GO(K, A, B, 4);                          \
-        else TOYNI_PASS_GO(K, A, B, 3);                                                \
+        else if (log_tiles32 >= 7 || LQ > 0) TOYNI_PASS_GO(K, A, B, 4);                \
+        else { if constexpr (LQ == 0) TOYNI_PASS_GO(K, A, B, 3); }                     \
         return true;                                                                   \
     }
     // The 128-, 256- and 512-point passes (three-pass plans n >= 2^21, two-pass plans up to 2^19) are memory-bound, and the strided
@@ -270,17 +272,27 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
     TOYNI_PASS_CASE_WIDE(KIND_ROW_T, 4, 4, 6)
     TOYNI_PASS_CASE_WIDE(KIND_ROW_T, 5, 4, TOYNI_WIDE_54)
     TOYNI_PASS_CASE_W(KIND_ROW_T, 5, 5)
-    // single-pass transforms (n <= 1024): one row per batch entry
-    TOYNI_PASS_CASE(KIND_ROW_N, 1, 0, 6)
-    TOYNI_PASS_CASE(KIND_ROW_N, 2, 0, 6)
-    TOYNI_PASS_CASE(KIND_ROW_N, 3, 0, 6)
-    TOYNI_PASS_CASE(KIND_ROW_N, 4, 0, 6)
-    TOYNI_PASS_CASE(KIND_ROW_N, 5, 0, 6)
-    TOYNI_PASS_CASE(KIND_ROW_N, 3, 3, 5)
-    TOYNI_PASS_CASE(KIND_ROW_N, 4, 3, 5)
-    TOYNI_PASS_CASE(KIND_ROW_N, 4, 4, 4)
-    TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 4)
-    TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
+    // single-pass transforms (n <= 1024): one row per batch entry.  Rows under 256 words never take the non-temporal kernels (the
+    // launcher's rule, toyni_hip.hip: enqueue_transform), so those twins are not instantiated
+#define TOYNI_PASS_CASE_PLAIN(K, A, B, LC_) \
+    if (kind == K && log_m == (A) + (B)) { f(Pass<K, A, B, LC_, false, LQ>{}); return true; }
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 1, 0, 6)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 2, 0, 6)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 3, 0, 6)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 4, 0, 6)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 5, 0, 6)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 3, 3, 5)
+    TOYNI_PASS_CASE_PLAIN(KIND_ROW_N, 4, 3, 5)
+#undef TOYNI_PASS_CASE_PLAIN
+    if constexpr (LQ == 0) {
+        TOYNI_PASS_CASE(KIND_ROW_N, 4, 4, 4)
+        TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 4)
+        TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 3)
+    } else {   // interleaved rows: 32 virtual rows = 8 Ext vectors per tile (>= 8 rows per coordinate: Pass::lds_row)
+        TOYNI_PASS_CASE(KIND_ROW_N, 4, 4, 5)
+        TOYNI_PASS_CASE(KIND_ROW_N, 5, 4, 5)
+        TOYNI_PASS_CASE(KIND_ROW_N, 5, 5, 5)
+    }
 #undef TOYNI_PASS_CASE
 #undef TOYNI_PASS_CASE_WIDE
 #undef TOYNI_PASS_CASE_W
@@ -290,7 +302,7 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
 
 // First pass of a low-degree extension (zero-padded input, PassArgs::in_prefix_log): the same column shapes with the
 // zero fraction as a compile-time parameter, f(Pass{}, std::integral_constant<int, LZ>{}), LZ = 1..5.
-template <class F>
+template <int LQ = 0, class F>
 inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
 #define TOYNI_LZ_CASES(PASS)                                                                 \
     switch (lz) {                                                                            \
@@ -302,20 +314,22 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
         default: return false;                                                               \
     }
 #define TOYNI_COMMA ,
-    if (log_m == 11) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
-    if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
-        if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
-        if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
-        if (log_m == 10) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+    if constexpr (LQ == 0) {
+        if (log_m == 11) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+        if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
+            if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
+            if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+            if (log_m == 10) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+        }
     }
-    if (log_m == 6) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
-    if (log_m == 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 5>) }
-    if (log_m == 8) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 5>) }
-    if (log_m == 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 4 TOYNI_COMMA 5>) }
+    if (log_m == 6) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 5 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+    if (log_m == 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 5 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+    if (log_m == 8) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 5 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+    if (log_m == 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 4 TOYNI_COMMA 5 TOYNI_COMMA false TOYNI_COMMA LQ>) }
     if (log_m == 10) {
-        if (log_tiles32 >= 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 5>) }
-        else if (log_tiles32 >= 7) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 4>) }
-        else { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 3>) }
+        if (log_tiles32 >= 9) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+        else if (log_tiles32 >= 7 || LQ > 0) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 4 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+        else { if constexpr (LQ == 0) { TOYNI_LZ_CASES(Pass<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 5 TOYNI_COMMA 3>) } }
     }
 #undef TOYNI_COMMA
 #undef TOYNI_LZ_CASES
@@ -339,7 +353,9 @@ struct CosetTables {
 // lde_log > 0 (forward, multi-pass plans only): `src` holds the n >> lde_log leading words of every transform, the
 // rest of the input is implied zeros -- the first pass runs its zero-aware variant (launch receives LZ = min(lde_log, 5)
 // as std::integral_constant; 0 for every other launch).
-template <class Launch>
+// LQ > 0: `batch` counts base-field transforms, Q = 2^LQ of them interleaved word by word (batch = Q x the number of Ext vectors;
+// src / work / dst hold batch * n words in the [vector][element][Q] layout): the interleaved variants of the same passes.
+template <int LQ = 0, class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
                           uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables(),
                           int lde_log = 0, bool nt = false) {
@@ -356,8 +372,8 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
         a.tw_lo = tables + pp.lo_off;
         a.tw_hi = tables + pp.hi_off;
         a.tw_lowbits = pp.lowbits;
-        a.log_S = (uint32_t)pp.log_s;
-        a.in_prefix_log = (uint32_t)(pp.log_s + pp.log_m - (p == 0 ? lde_log : 0));
+        a.log_S = (uint32_t)(pp.log_s + LQ);   // interleaved: Q words per column position (the twiddle column is column >> LQ)
+        a.in_prefix_log = (uint32_t)(pp.log_s + pp.log_m - (p == 0 ? lde_log : 0) + LQ);
         a.nz_rows = (1u << pp.log_m) >> (p == 0 ? lde_log : 0);
         a.scale = (inverse && p == 0) ? plan.scale_inv : 0u;  // src/ntt.rs:62-65, fused
         a.log_n = (uint32_t)plan.log_n;
@@ -392,8 +408,8 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
             launch(pass, lzc, a, nblocks);
         };
         bool ok;
-        if (p == 0 && lde_log) ok = dispatch_pass_lz(pp.log_m, log_tiles32, lde_log < 5 ? lde_log : 5, body);
-        else ok = dispatch_pass(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); }, nt);
+        if (p == 0 && lde_log) ok = dispatch_pass_lz<LQ>(pp.log_m, log_tiles32, lde_log < 5 ? lde_log : 5, body);
+        else ok = dispatch_pass<LQ>(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); }, nt);
         if (!ok) return false;
     }
     return true;

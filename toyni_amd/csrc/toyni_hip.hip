@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -23,7 +24,41 @@
 
 using namespace toyni;
 
-#define HIPCHK(expr)                                   \
+// ------------------------------------------------------------------------------------------------
+// launch registry (toyni_launched_kernels, include/toyni_hip.h section 4)
+// ------------------------------------------------------------------------------------------------
+// Every launch site of this translation unit goes through the macro below: the FIRST launch of a site resolves the kernel's symbol
+// (hipKernelNameRefByPtr) and files it; every later one costs a relaxed load of a site-local flag.  tests/test_zz_kernel_coverage.py
+// compares the registry of a finished GPU test session with the kernel symbols of the shipped binary, so "every kernel the launcher
+// can pick has been through the parity tests" is a test, not a sentence.  TOYNI_LAUNCH_LOG=<file>: every newly filed
+// symbol is also appended to that file, so child processes of a test session (other dispatch knobs, the measurement build) count.
+namespace launch_registry {
+inline std::mutex& mu() { static std::mutex m; return m; }
+inline std::vector<std::string>& names() { static std::vector<std::string> v; return v; }
+inline void note(const void* host_fn) {
+    const char* nm = hipKernelNameRefByPtr(host_fn, nullptr);
+    if (!nm) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(mu());
+    for (const auto& s : names())
+        if (s == nm) return;
+    names().push_back(nm);
+    if (const char* path = std::getenv("TOYNI_LAUNCH_LOG")) {
+        if (FILE* f = std::fopen(path, "a")) { std::fprintf(f, "%s\n", nm); std::fclose(f); }
+    }
+}
+}  // namespace launch_registry
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                      \
+    do {                                                                                                 \
+        static std::atomic<bool> _toyni_site_seen{false};                                                \
+        if (!_toyni_site_seen.load(std::memory_order_relaxed)) {                                         \
+            _toyni_site_seen.store(true, std::memory_order_relaxed);                                     \
+            launch_registry::note(reinterpret_cast<const void*>(kernel));                                \
+        }                                                                                                \
+        kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                                     \
+    } while (0)
+
+#define HIPCHK(expr)                                 \
     do {                                               \
         hipError_t _e = (expr);                        \
         if (_e != hipSuccess) return (int)_e;          \
@@ -41,7 +76,7 @@ using namespace toyni;
 //     behind them -- all of it BEFORE the current tile's stores, in flight across the barrier and the whole of step 2.
 // The barriers are raw s_barrier with an explicit LDS-only wait: __syncthreads() would also drain vmcnt.
 template <class P> struct PassKindOf;
-template <int K, int A, int B, int C, bool N> struct PassKindOf<Pass<K, A, B, C, N>> { static constexpr int value = K; };
+template <int K, int A, int B, int C, bool N, int Q> struct PassKindOf<Pass<K, A, B, C, N, Q>> { static constexpr int value = K; };
 template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
 
 // LZ > 0: first pass of a low-degree extension -- the input holds only the leading n >> LZ words of every transform
@@ -224,26 +259,6 @@ __global__ void __launch_bounds__(256) narrow_nonzero_kernel(const uint64_t* __r
 __global__ void __launch_bounds__(256) widen_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = in[i];
-}
-
-// Ext (4 coordinates per element, AoS) <-> four base-field columns (SoA): the de-interleave / recombine of
-// BabyBearDomain::transform_ext (src/math/domain.rs:140-151), on the device.  IN = uint64_t (host layout, reduced) or uint32_t.
-template <class IN>
-__global__ void __launch_bounds__(256) ext_split_kernel(const IN* __restrict__ aos, uint32_t* __restrict__ soa, size_t n, size_t col_stride) {
-    // n elements in; coordinate k goes to soa[k * col_stride ..] (col_stride >= n: a compact LDE input is padded to a power of two)
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) soa[(size_t)k * col_stride + i] = (uint32_t)(aos[4 * i + k] % BB_P);
-    }
-}
-template <class OUT>
-__global__ void __launch_bounds__(256) ext_join_kernel(const uint32_t* __restrict__ soa, OUT* __restrict__ aos, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) aos[4 * i + k] = soa[(size_t)k * n + i];
-    }
 }
 
 // 4-step twiddle: data[r][k] *= w_n^(+-(row0 + r) k), r < rows, k < row_len (two-level domain table of the ctx)
@@ -1134,12 +1149,18 @@ int prefetch_depth() {
     return depth;
 }
 
+// prefetch depth of the interleaved (Ext) shapes: the prefetching kernel, except the single-pass 1024-point shape (32 virtual rows
+// per tile: with the next tile's 32 loads in flight it needs 128 VGPRs + 100 B of scratch; without them it fits)
+template <class P> constexpr int ext_prefetch() { return (kind_of<P>() == KIND_ROW_N && P::LM == 10) ? 0 : 32; }
+
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
     if constexpr (P::STEPS == 3) {
         hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else if constexpr (LZ > 0) {  // LDE first pass: one kernel each
         hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+    } else if constexpr (P::LQ > 0) {  // interleaved (Ext) shapes: one kernel each (no A/B twin)
+        hipLaunchKernelGGL((ntt_pass_kernel<P, ext_prefetch<P>()>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else {
         if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
         else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
@@ -1154,6 +1175,7 @@ unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
         int occ = 0;
         hipError_t qe;
         if constexpr (P::STEPS == 3) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3_kernel<P, 0>, (int)P::T, 0);
+        else if constexpr (P::LQ > 0) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, ext_prefetch<P>()>, (int)P::T, 0);
         else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0);
         if (qe != hipSuccess || occ < 1) occ = 1;
         if (const char* env = std::getenv("TOYNI_WG_PER_CU")) { int v = std::atoi(env); if (v > 0) occ = v; }
@@ -1195,9 +1217,12 @@ int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 
 // Enqueue the passes of `batch` transforms on stream s (d_in == d_out allowed).  shift != 1: the coset scaling of
 // BabyBearDomain::fft / ifft is fused into the first / last pass.
+// lq = 2: `batch` Ext vectors in the reference's AoS layout ([n][4] words each; lde_log > 0: [n >> lde_log][4] in): the interleaved
+// variants of the same passes (Pass<..., LQ = 2>), i.e. fft_ext / ifft_ext (src/math/domain.rs:129-151) without a de-interleave.
 int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, bool inverse, hipStream_t s, uint32_t shift = 1u,
-                      int lde_log = 0) {
+                      int lde_log = 0, int lq = 0) {
     if (batch == 0) return 0;
+    batch <<= lq;   // from here on in base-field transforms (Q interleaved ones per Ext vector)
     toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     const size_t n = c->n;
     const size_t n_in = n >> lde_log;  // lde_log > 0: the input holds the leading n >> lde_log words of every transform
@@ -1216,7 +1241,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    if (lde_log == 0 && lds_kernel_enabled(c->plan, batch)) {
+    if (lde_log == 0 && lq == 0 && lds_kernel_enabled(c->plan, batch)) {
         // n = 2^11 .. 2^15: one sweep, the transform never leaves the workgroup's LDS (no intermediate buffer)
         hipError_t err = hipSuccess;
         const bool ok = lds_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch,
@@ -1233,7 +1258,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     }
     // a lone transform (or a few) of n = 2^21 / 2^22: the two-pass latency plan, while its first pass has at most
     // 2^lat_max_log_tiles32() 32-wide tiles' worth of columns
-    const bool lat = c->has_lat && pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
+    const bool lat = lq == 0 && c->has_lat && pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
                      (((uint64_t)batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32()) &&
                      (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
     const NttPlan& plan = lat ? c->plan_lat : c->plan;
@@ -1241,6 +1266,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     if (c->chunk_elems && c->plan.npasses > 1) {
         chunk = c->chunk_elems / n;
         if (chunk < 1) chunk = 1;
+        if (lq) chunk = ((chunk + 3) >> 2) << 2;   // whole Ext vectors
         if (chunk > batch) chunk = batch;
     }
     if (c->plan.npasses > 1) {
@@ -1257,16 +1283,17 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
         hipError_t err = hipSuccess;
         int pass_index = 0;
-        bool ok = for_each_pass(plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb,
-                                [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
-                                    using P = decltype(pass);
-                                    constexpr int LZ = decltype(lzc)::value;
-                                    const int p = pass_index++;
-                                    if (err != hipSuccess) return;
-                                    TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, p);
-                                    launch_pass<P, LZ>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
-                                    err = hipGetLastError();
-                                }, cs, lde_log, nt);
+        auto launch = [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
+            using P = decltype(pass);
+            constexpr int LZ = decltype(lzc)::value;
+            const int p = pass_index++;
+            if (err != hipSuccess) return;
+            TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, p);
+            launch_pass<P, LZ>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
+            err = hipGetLastError();
+        };
+        bool ok = lq ? for_each_pass<2>(plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb, launch, cs, lde_log, nt)
+                     : for_each_pass<0>(plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb, launch, cs, lde_log, nt);
         if (!ok) return TOYNI_E_INVALID_SIZE;
         if (err != hipSuccess) return (int)err;
     }
@@ -1368,6 +1395,25 @@ int toyni_device_count(int* count) {
 int cudaGetDeviceCount(int* count) { return toyni_device_count(count); }
 
 int toyni_set_device(int device) { return (int)hipSetDevice(device); }
+
+// newline-separated symbols of every kernel this process has launched through the library so far; returns the bytes needed
+// (including the terminating 0) -- call with (nullptr, 0) for the size.  Diagnostics: tests/test_zz_kernel_coverage.py.
+size_t toyni_launched_kernels(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(launch_registry::mu());
+    size_t need = 1;
+    for (const auto& s : launch_registry::names()) need += s.size() + 1;
+    if (buf && cap) {
+        size_t at = 0;
+        for (const auto& s : launch_registry::names()) {
+            if (at + s.size() + 1 >= cap) break;
+            std::memcpy(buf + at, s.data(), s.size());
+            at += s.size();
+            buf[at++] = '\n';
+        }
+        buf[at] = 0;
+    }
+    return need;
+}
 
 int toyni_ntt_ctx_create(uint32_t n, int device, toyni_ntt_ctx** out) {
     if (!out) return TOYNI_E_NULL;
@@ -1511,16 +1557,18 @@ int toyni_coset_ntt_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_o
 // Low-degree extension (src/fibonacci.rs:101-103 / BabyBearDomain::fft on a coefficient vector shorter than the domain,
 // src/math/domain.rs:107-123): forward coset transform of coefficients zero-padded to n.  The padding is never
 // materialised: the first pass reads the n >> log_blowup words that exist and skips the butterflies whose partner is zero.
-static int enqueue_lde(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, hipStream_t s) {
-    if (log_blowup == 0) return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift);
+// lq = 2: `batch` Ext vectors, AoS on both sides (enqueue_transform)
+static int enqueue_lde(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, hipStream_t s,
+                       int lq = 0) {
+    if (log_blowup == 0) return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift, 0, lq);
     if (c->plan.npasses >= 2 && (int)log_blowup <= c->plan.pass[0].log_m)
-        return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift, (int)log_blowup);
+        return enqueue_transform(c, d_coeffs, d_out, batch, false, s, shift, (int)log_blowup, lq);
     // single-pass sizes (n <= 1024) and blow-ups beyond the first pass: materialise the padding, transform in place
     if (batch == 0) return TOYNI_OK;
-    const size_t n = c->n, n_in = n >> log_blowup;
+    const size_t n = (size_t)c->n << lq, n_in = n >> log_blowup;   // words per vector
     HIPCHK(hipMemsetAsync(d_out, 0, batch * n * sizeof(uint32_t), s));
     HIPCHK(hipMemcpy2DAsync(d_out, n * sizeof(uint32_t), d_coeffs, n_in * sizeof(uint32_t), n_in * sizeof(uint32_t), batch, hipMemcpyDeviceToDevice, s));
-    return enqueue_transform(c, d_out, d_out, batch, false, s, shift);
+    return enqueue_transform(c, d_out, d_out, batch, false, s, shift, 0, lq);
 }
 
 int toyni_lde_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream) {
@@ -1689,7 +1737,8 @@ static int host_transform(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint
 
 int toyni_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, int inverse) { return host_transform(c, h_data, batch, 1u, inverse); }
 
-// fft_ext / ifft_ext (src/math/domain.rs:129-151): one call, one PCIe round trip, the four coordinate transforms as ONE batch of 4
+// fft_ext / ifft_ext (src/math/domain.rs:129-151) on host slices: one call, one PCIe round trip.  The reference de-interleaves the
+// four coordinates, transforms each and re-interleaves (:140-151); here the AoS vector goes through the interleaved passes as it is.
 int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int inverse) {
     if (!c || !h_data) return TOYNI_E_NULL;
     shift %= BB_P;
@@ -1703,9 +1752,9 @@ int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int i
     if ((rc = grow(c, s, (void**)&sc.d_stage64, &sc.stage64_elems, total, sizeof(uint64_t)))) return rc;
     if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, total, sizeof(uint32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(sc.d_stage64, h_data, total * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_stage64, sc.d_data32, n, n);
-    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, 4, inverse != 0, s, (uint32_t)shift))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, n);
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(total)), dim3(256), 0, s, sc.d_stage64, sc.d_data32, total);
+    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, 1, inverse != 0, s, (uint32_t)shift, 0, 2))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(total)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, total);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_data, sc.d_stage64, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1713,21 +1762,22 @@ int toyni_ntt_ext_host(toyni_ntt_ctx* c, uint64_t* h_data, uint64_t shift, int i
     return TOYNI_OK;
 }
 
-// device-resident Ext transform on AoS packed u32 (n elements x 4 coordinates), in place
-int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int inverse, void* stream) {
-    if (!c || !d_data) return TOYNI_E_NULL;
+// device-resident Ext transforms on AoS packed u32 (batch vectors of n elements x 4 coordinates): exactly the plan's passes, no
+// de-interleave (round 4; rounds 2-3 split into four columns, ran a batch of 4 and joined: two extra sweeps)
+int toyni_ntt_ext_batch_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, size_t batch, uint32_t shift, int inverse, void* stream) {
+    if (!c || !d_in || !d_out) return TOYNI_E_NULL;
     if (shift == 0 || shift >= BB_P) return TOYNI_E_RANGE;
     TOYNI_CTX_LOCK(c);
     DeviceGuard guard(c->device);
-    const size_t n = c->n;
-    hipStream_t s = (hipStream_t)stream;
-    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
-    int rc;
-    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, d_data, sc.d_data32, n, n);
-    if ((rc = enqueue_transform(c, sc.d_data32, sc.d_data32, 4, inverse != 0, s, shift))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, d_data, n);
-    return (int)hipGetLastError();
+    if (c->plan.log_n == 0) {   // n = 1: the identity on every coordinate
+        if (d_in != d_out && batch) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return TOYNI_OK;
+    }
+    return enqueue_transform(c, d_in, d_out, batch, inverse != 0, (hipStream_t)stream, shift, 0, 2);
+}
+
+int toyni_ntt_ext_device(toyni_ntt_ctx* c, uint32_t* d_data, uint32_t shift, int inverse, void* stream) {
+    return toyni_ntt_ext_batch_device(c, d_data, d_data, 1, shift, inverse, stream);
 }
 
 int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint64_t shift, int inverse) {
@@ -1735,30 +1785,23 @@ int toyni_coset_ntt_host(toyni_ntt_ctx* c, uint64_t* h_data, size_t batch, uint6
     return host_transform(c, h_data, batch, (uint32_t)shift, inverse);
 }
 
-// fft_ext of a short coefficient vector (src/math/domain.rs:134-151 pads each coordinate column to the domain size): the
-// four coordinate columns as one batch-of-4 low-degree extension, padding implied
-static int enqueue_lde_ext(toyni_ntt_ctx* c, size_t compact, uint32_t shift, hipStream_t s) {
-    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
-    // in: sc.d_lde32 = [4][compact] coordinate columns; out: sc.d_data32 = [4][n]
-    const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
-    return enqueue_lde(c, sc.d_lde32, sc.d_data32, 4, log_blowup, shift, s);
+// fft_ext of short coefficient vectors (src/math/domain.rs:134-151 pads each coordinate column to the domain size): `batch` AoS vectors
+// of n >> log_blowup Ext coefficients in, n Ext evaluations each out -- the interleaved low-degree extension, padding implied
+int toyni_lde_ext_batch_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, size_t batch, unsigned log_blowup, uint32_t shift, void* stream) {
+    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
+    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n || (log_blowup && d_coeffs == d_out)) return TOYNI_E_RANGE;
+    TOYNI_CTX_LOCK(c);
+    DeviceGuard guard(c->device);
+    if (c->plan.log_n == 0) {
+        if (d_coeffs != d_out && batch) HIPCHK(hipMemcpyAsync(d_out, d_coeffs, batch * 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return TOYNI_OK;
+    }
+    return enqueue_lde(c, d_coeffs, d_out, batch, log_blowup, shift, (hipStream_t)stream, 2);
 }
 
 int toyni_lde_ext_device(toyni_ntt_ctx* c, const uint32_t* d_coeffs, uint32_t* d_out, unsigned log_blowup, uint32_t shift, void* stream) {
-    if (!c || !d_coeffs || !d_out) return TOYNI_E_NULL;
-    if (shift == 0 || shift >= BB_P || (int)log_blowup > c->plan.log_n || d_coeffs == d_out) return TOYNI_E_RANGE;
-    TOYNI_CTX_LOCK(c);
-    DeviceGuard guard(c->device);
-    hipStream_t s = (hipStream_t)stream;
-    toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
-    const size_t n = c->n, n_in = n >> log_blowup;
-    int rc;
-    if ((rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, 4 * n_in, sizeof(uint32_t)))) return rc;
-    if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
-    hipLaunchKernelGGL(ext_split_kernel<uint32_t>, dim3(grid_for(n_in)), dim3(256), 0, s, d_coeffs, sc.d_lde32, n_in, n_in);
-    if ((rc = enqueue_lde_ext(c, n_in, shift, s))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, d_out, n);
-    return (int)hipGetLastError();
+    if (d_coeffs && d_coeffs == d_out) return TOYNI_E_RANGE;
+    return toyni_lde_ext_batch_device(c, d_coeffs, d_out, 1, log_blowup, shift, stream);
 }
 
 int toyni_lde_ext_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeffs, uint64_t* h_out, uint64_t shift) {
@@ -1771,6 +1814,7 @@ int toyni_lde_ext_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeff
     if (ncoeffs == 0) { std::memset(h_out, 0, 4 * n * sizeof(uint64_t)); return TOYNI_OK; }
     size_t compact = 1;
     while (compact < ncoeffs) compact <<= 1;
+    const unsigned log_blowup = (unsigned)(c->plan.log_n - ilog2(compact));
     hipStream_t s = c->stream;
     toyni_ntt_ctx::Scratch& sc = scratch_for(c, s);
     int rc;
@@ -1778,10 +1822,11 @@ int toyni_lde_ext_host(toyni_ntt_ctx* c, const uint64_t* h_coeffs, size_t ncoeff
     if ((rc = grow(c, s, (void**)&sc.d_data32, &sc.data32_words, 4 * n, sizeof(uint32_t)))) return rc;
     if ((rc = grow(c, s, (void**)&sc.d_lde32, &sc.lde32_words, 4 * compact, sizeof(uint32_t)))) return rc;
     HIPCHK(hipMemcpyAsync(sc.d_stage64, h_coeffs, 4 * ncoeffs * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(sc.d_lde32, 0, 4 * compact * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(ext_split_kernel<uint64_t>, dim3(grid_for(ncoeffs)), dim3(256), 0, s, sc.d_stage64, sc.d_lde32, ncoeffs, compact);
-    if ((rc = enqueue_lde_ext(c, compact, (uint32_t)shift, s))) return rc;
-    hipLaunchKernelGGL(ext_join_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, n);
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(4 * ncoeffs)), dim3(256), 0, s, sc.d_stage64, sc.d_lde32, 4 * ncoeffs);
+    if (compact > ncoeffs) HIPCHK(hipMemsetAsync(sc.d_lde32 + 4 * ncoeffs, 0, 4 * (compact - ncoeffs) * sizeof(uint32_t), s));
+    if (c->plan.log_n == 0) HIPCHK(hipMemcpyAsync(sc.d_data32, sc.d_lde32, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    else if ((rc = enqueue_lde(c, sc.d_lde32, sc.d_data32, 1, log_blowup, (uint32_t)shift, s, 2))) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3(grid_for(4 * n)), dim3(256), 0, s, sc.d_data32, sc.d_stage64, 4 * n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, sc.d_stage64, 4 * n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1918,24 +1963,15 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     } else if ((f.half & 3) == 0 && m >= ((uint64_t)1 << 26) && fold_shape() != 0) {
         // (layers of >= 256 MiB: measured +22 % at 2^26 and +10 % at 2^27 elements; a cache-resident 2^24 layer is 5 % FASTER on the
         // 256-thread kernel below -- 5.95 against 5.63 TB/s -- so smaller layers keep it)
-        // large layers: the shaped stream.  TOYNI_FOLD_SHAPE (A/B knob) = 0: round 2's kernel; 1: 1024 threads x 4 in flight; 2 (default):
-        // 1024 x 2; 3: 512 x 4; 4: 256 x 4.  Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for the
-        // round-2 kernel, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4.
+        // large layers: the shaped stream, 1024 threads x 2 load pairs in flight.  TOYNI_FOLD_SHAPE=0 (A/B knob): round 2's kernel.
+        // Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for the round-2 kernel, 5.83 for its
+        // shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4 -- only the winner is instantiated.
         const bool nt = (uint64_t)m * sizeof(uint32_t) >= nt_min_bytes();
-        const uint64_t quads = f.half / 4;
-        auto grid = [&](uint64_t chunk) { uint64_t g = (quads + chunk - 1) / chunk; const uint64_t cap = (uint64_t)c->num_cus * 8; return (unsigned)(g > cap ? cap : g); };
-#define TOYNI_FOLD_GO(T_, U_)                                                                                                         \
-    do {                                                                                                                              \
-        if (nt) hipLaunchKernelGGL((fri_fold_stream_kernel<true, T_, U_>), dim3(grid((uint64_t)T_ * U_)), dim3(T_), 0, s, f);         \
-        else hipLaunchKernelGGL((fri_fold_stream_kernel<false, T_, U_>), dim3(grid((uint64_t)T_ * U_)), dim3(T_), 0, s, f);           \
-    } while (0)
-        switch (fold_shape()) {
-            case 1: TOYNI_FOLD_GO(1024, 4); break;
-            case 2: TOYNI_FOLD_GO(1024, 2); break;
-            case 3: TOYNI_FOLD_GO(512, 4); break;
-            default: TOYNI_FOLD_GO(256, 4); break;
-        }
-#undef TOYNI_FOLD_GO
+        const uint64_t quads = f.half / 4, chunk = 1024 * 2, cap = (uint64_t)c->num_cus * 8;
+        uint64_t g = (quads + chunk - 1) / chunk;
+        if (g > cap) g = cap;
+        if (nt) hipLaunchKernelGGL((fri_fold_stream_kernel<true, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
+        else hipLaunchKernelGGL((fri_fold_stream_kernel<false, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
     } else if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) {
         hipLaunchKernelGGL((fri_fold_kernel<true, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     } else {

@@ -161,6 +161,33 @@ class HipLocalOps:
               "slab relayout failed")
 
 
+class PhaseClock:
+    """Optional per-phase timing of the multi-device forms (bench.py): `mark(name)` records a HIP event on the device's current stream
+    and charges the time since the previous mark to `name`.  The collective is stream-ordered against the current stream, so the mark
+    behind it fires when the exchange has landed.  `ms()` waits for the device and returns {name: milliseconds summed over all marks}."""
+
+    def __init__(self, device):
+        self.device, self.marks = device, []
+
+    def mark(self, name: str) -> None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.marks.append((name, ev))
+
+    def ms(self) -> dict:
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for (_, e0), (name, e1) in zip(self.marks, self.marks[1:]):
+            if name != "start":
+                out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def _mark(clock, name: str) -> None:
+    if clock is not None:
+        clock.mark(name)
+
+
 def _exchange(send: torch.Tensor, group=None) -> torch.Tensor:
     """The one all-to-all: send[h] goes to rank h; returns recv with recv[g] from rank g."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
@@ -170,38 +197,56 @@ def _exchange(send: torch.Tensor, group=None) -> torch.Tensor:
     return recv
 
 
-def fourstep_forward(cols: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+def fourstep_forward(cols: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, clock=None) -> torch.Tensor:
     """cols: [n1, n2/G] int32 (element (j1, jc) = x[j1*n2 + rank*n2/G + jc]).  Returns [n1/G, n2] (see fourstep_output_index)."""
     l1, l2 = fourstep_split(log_n, world)
     n1, n2 = 1 << l1, 1 << l2
     c, r = n2 // world, n1 // world
     assert cols.shape == (n1, c)
+    _mark(clock, "start")
     t = cols.t().contiguous()                      # [c, n1]: row = column j2 of the matrix
     if t.data_ptr() == cols.data_ptr():            # a one-column block transposes to a view: do not overwrite the caller's input
         t = t.clone()
+    _mark(clock, "transpose_pack")
     ops.ntt_rows(t, False)                         # n1-point transforms over j1
+    _mark(clock, "local_transforms")
     ops.twiddle(t, rank * c, False)                # * w_n^(j2 k1)
+    _mark(clock, "twiddle")
     send = t.view(c, world, r).permute(1, 0, 2).contiguous()   # [G, c, r]: block h = k1 in rank h's chunk
+    _mark(clock, "transpose_pack")
     recv = _exchange(send, group)                  # [G, c, r]: block g = j2 in rank g's chunk
+    _mark(clock, "exchange")
     rows = recv.permute(2, 0, 1).reshape(r, n2).contiguous()   # [k1_local, j2]
+    _mark(clock, "transpose_pack")
     ops.ntt_rows(rows, False)                      # n2-point transforms over j2
+    _mark(clock, "local_transforms")
     return rows
 
 
-def fourstep_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None) -> torch.Tensor:
+def fourstep_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, clock=None) -> torch.Tensor:
     """Mirror of fourstep_forward: [n1/G, n2] block of X -> [n1, n2/G] column block of x."""
     l1, l2 = fourstep_split(log_n, world)
     n1, n2 = 1 << l1, 1 << l2
     c, r = n2 // world, n1 // world
     assert rows.shape == (r, n2)
+    _mark(clock, "start")
     b = rows.contiguous().clone()
+    _mark(clock, "transpose_pack")
     ops.ntt_rows(b, True)                          # inverse n2-point over k2 -> [k1_local, j2], scaled by n2^-1
+    _mark(clock, "local_transforms")
     send = b.view(r, world, c).permute(1, 2, 0).contiguous()   # [G, c, r]: block h = j2 in rank h's chunk
+    _mark(clock, "transpose_pack")
     recv = _exchange(send, group)                  # [G, c, r]: block g = k1 in rank g's chunk
+    _mark(clock, "exchange")
     t = recv.permute(1, 0, 2).reshape(c, n1).contiguous()      # [jc, k1]
+    _mark(clock, "transpose_pack")
     ops.twiddle(t, rank * c, True)                 # * w_n^-(j2 k1)
+    _mark(clock, "twiddle")
     ops.ntt_rows(t, True)                          # inverse n1-point over k1, scaled by n1^-1
-    return t.t().contiguous()
+    _mark(clock, "local_transforms")
+    out = t.t().contiguous()
+    _mark(clock, "transpose_pack")
+    return out
 
 
 def _exchange_blocks_async(send_blocks, recv_blocks, rank: int, world: int, group=None):
@@ -219,7 +264,7 @@ def _exchange_blocks_async(send_blocks, recv_blocks, rank: int, world: int, grou
     return dist.batch_isend_irecv(p2p)
 
 
-def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1) -> torch.Tensor:
+def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1, clock=None) -> torch.Tensor:
     """slab: [M1, S1/G] int32, element (j1, c) = x[j1*S1 + rank*S1/G + c]; OVERWRITTEN.  Returns [M1/G, S1] (slab_output_index).
 
     chunks > 1: the exchange is issued as `chunks` asynchronous pieces (sub-blocks of every destination's row block) and
@@ -228,12 +273,17 @@ def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
     m1, s1 = 1 << l1, 1 << ls
     w, r = s1 // world, m1 // world
     assert slab.shape == (m1, w) and slab.is_contiguous()
+    _mark(clock, "start")
     ops.slab_pass(slab, rank * w, False)           # M1-point column transforms * w_n^(j' k1), in place, no transpose
+    _mark(clock, "slab_pass")
     rows = torch.empty((r, s1), dtype=slab.dtype, device=slab.device)
     if chunks <= 1:
         recv = _exchange(slab.view(world, r, w), group)  # row block h (k1 in rank h's chunk) is contiguous: no packing
+        _mark(clock, "exchange")
         ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
+        _mark(clock, "relayout")
         ops.ntt_rows(rows, False)                  # what is left: size-S1 transforms over j'
+        _mark(clock, "row_transforms")
         return rows
     assert chunks & (chunks - 1) == 0 and r % chunks == 0, "chunks must be a power of two dividing the rows per rank"
     rq = r // chunks
@@ -249,21 +299,26 @@ def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
         part = rows[q * rq:(q + 1) * rq]
         ops.relayout(recv_q, part, rq, rank * r + q * rq, world, False)
         ops.ntt_rows(part, False)
+    _mark(clock, "exchange_relayout_rows_pipelined")
     return rows
 
 
-def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1) -> torch.Tensor:
+def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int = 1, group=None, chunks: int = 1, clock=None) -> torch.Tensor:
     """Mirror of slab_forward: [M1/G, S1] block of X (OVERWRITTEN) -> [M1, S1/G] slab of x.  chunks > 1: piece q is on the
     wire while the row transforms of piece q+1 run."""
     l1, ls = slab_split(log_n, world)
     m1, s1 = 1 << l1, 1 << ls
     w, r = s1 // world, m1 // world
     assert rows.shape == (r, s1) and rows.is_contiguous()
+    _mark(clock, "start")
     if chunks <= 1:
         ops.ntt_rows(rows, True)                   # inverse size-S1 over k', scaled by 1/S1
+        _mark(clock, "row_transforms")
         send = torch.empty((world, r, w), dtype=rows.dtype, device=rows.device)
         ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
+        _mark(clock, "relayout")
         slab = _exchange(send, group).view(m1, w)  # block g = k1 in rank g's chunk: the [M1][w] slab
+        _mark(clock, "exchange")
     else:
         assert chunks & (chunks - 1) == 0 and r % chunks == 0, "chunks must be a power of two dividing the rows per rank"
         rq = r // chunks
@@ -279,5 +334,7 @@ def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
             keep.append(send_q)                    # alive until the sends have completed
         for wk in works:
             wk.wait()
+        _mark(clock, "exchange_relayout_rows_pipelined")
     ops.slab_pass(slab, rank * w, True)            # inverse M1-point column transforms, scaled by 1/M1
+    _mark(clock, "slab_pass")
     return slab

@@ -168,6 +168,14 @@ class NttContext:
     def run_device_ext(self, d_data: int, inverse: bool, shift: int = 1, stream: int = 0) -> None:
         check(lib.toyni_ntt_ext_device(self.handle, d_data, shift, int(inverse), stream or None), "GPU Ext NTT failed")
 
+    def run_device_ext_batch(self, d_in: int, d_out: int, batch: int, inverse: bool, shift: int = 1, stream: int = 0) -> None:
+        """fft_ext / ifft_ext of `batch` Ext vectors (packed u32 AoS, [batch][n][4]) through the interleaved passes; d_in == d_out allowed."""
+        check(lib.toyni_ntt_ext_batch_device(self.handle, d_in, d_out, batch, shift, int(inverse), stream or None), "GPU Ext NTT failed")
+
+    def lde_ext_device(self, d_coeffs: int, d_out: int, batch: int, log_blowup: int, shift: int = 1, stream: int = 0) -> None:
+        """fft_ext of `batch` vectors of n >> log_blowup Ext coefficients (AoS) on the coset shift * <w_n>, zero padding implied."""
+        check(lib.toyni_lde_ext_batch_device(self.handle, d_coeffs, d_out, batch, log_blowup, shift, stream or None), "GPU Ext LDE failed")
+
     def run_device_u64(self, d_data: int, batch: int, inverse: bool, stream: int = 0) -> None:
         check(lib.toyni_ntt_device_u64(self.handle, d_data, batch, int(inverse), stream or None), "GPU NTT failed")
 
