@@ -825,13 +825,21 @@ def main():
                 # round 3 (fold_xs_batch): 46 products of the shared inversion per SIXTEEN outputs plus 6 per output (to Montgomery form,
                 # prefix product, two for the back-substitution, the coefficient, the application): ~9 per output = 4.5 per input element,
                 # 5 VALU instructions each, plus the adds, against the 39.3 T lane-ops/s of that instruction class
-                xs_lane_ops = 4.5 * 5 + 8
+                xs_lane_ops, xs_ops_src = 4.5 * 5 + 8, "hand count (no committed counter profile found)"
+                import glob as _glob
+                for cf in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_counters_fold_xs.json")), reverse=True):
+                    cj = json.load(open(cf))
+                    ks = [v for k, v in cj.get("kernels", {}).items() if "fri_fold_xs16_kernel" in k]
+                    if ks and cj.get("layer_log") == 24:
+                        xs_lane_ops = ks[0]["lane_ops_per_input_element"]
+                        xs_ops_src = stamp(f"profiles/{os.path.basename(cf)} (rocprofv3 --pmc SQ_INSTS_VALU, {ks[0]['dispatches']} launches of fri_fold_xs16_kernel on a 2^24 layer)", cf)
+                        break
                 xs_checked = verify_fold_samples(buf, o, nn, 123456789, xs_t=xs24)
                 extras["fri_fold_xs_m2^24"] = {
                     "us": t_xs * 1e6, "GBps": 8.0 * nn / t_xs / 1e9, "frac_of_hbm_peak": 8.0 * nn / t_xs / 1e9 / HBM_PEAK_GBPS,
                     "elements_per_s": nn / t_xs, "bound": "valu", "verified": True, "verified_outputs": xs_checked,
-                    "valu": {"lane_ops_per_input_element_estimate": xs_lane_ops, "achieved_Tops_estimate": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
-                             "frac_estimate": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
+                    "valu": {"lane_ops_per_input_element": xs_lane_ops, "source": xs_ops_src, "achieved_Tops": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
+                             "frac": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
                     "note": "toyni_fri_fold_xs_device on a 2^24 layer, explicit points resident in HBM; 8 B algorithmic per input element (4 evals + 2 xs "
                             "read, 2 written); one Fermat inversion per 16 outputs (src/math/fri.rs:38-40 inverts per element); round 2's 4-per-inversion kernel moved 3.0 TB/s"}
                 del xs24

@@ -250,3 +250,43 @@ def test_commit_phase_reports_a_failing_transcript(env):
     # a beta outside the field is refused, not reduced silently
     with pytest.raises(Exception):
         ta.prover.fri_commit_phase_device(ctx, te.data_ptr(), 64, 7, 1, 0, lambda r, root, w: P, layers.data_ptr(), levels.data_ptr())
+
+
+def test_commit_phase_refuses_reentry_also_after_a_nested_phase_on_another_context(env):
+    """A transcript callback runs with its context locked: an entry point on THAT context from inside it returns TOYNI_E_REENTRANT
+    instead of deadlocking -- also after the callback ran a whole commit phase on ANOTHER context (whose own callbacks come and go in
+    between; ADVICE r3: the guard used to be one thread-local slot, which the nested phase cleared)."""
+    ta, torch, dev = env
+    lib = ta._lib.lib
+    a, b = ta.NttContext(64, device=dev.index), ta.NttContext(32, device=dev.index)
+    ea, eb = _dev(torch, dev, oracle.splitmix(64, 2)), _dev(torch, dev, oracle.splitmix(32, 3))
+    la, lb = torch.empty(63, dtype=torch.int32, device=dev), torch.empty(31, dtype=torch.int32, device=dev)
+    va, vb = torch.zeros((200, 32), dtype=torch.uint8, device=dev), torch.zeros((100, 32), dtype=torch.uint8, device=dev)
+    scratch = torch.zeros(64, dtype=torch.int32, device=dev)
+    seen = {"inner_rounds": 0, "status": []}
+
+    def try_a():
+        return lib.toyni_ntt_device(a.handle, scratch.data_ptr(), scratch.data_ptr(), 1, 0, None)
+
+    def inner(rnd, root, want_beta):
+        seen["inner_rounds"] += 1
+        seen["status"].append(("inside B's callback, on A", try_a()))     # A's callback is still further up this thread's stack
+        return 9
+
+    def outer(rnd, root, want_beta):
+        if rnd == 1:
+            seen["status"].append(("before the nested phase", try_a()))
+            ta.prover.fri_commit_phase_device(b, eb.data_ptr(), 32, 7, 1, 0, inner, lb.data_ptr(), vb.data_ptr())
+            seen["status"].append(("after the nested phase", try_a()))
+            # B itself is free again once its phase has returned
+            assert lib.toyni_ntt_device(b.handle, scratch.data_ptr(), scratch.data_ptr(), 1, 0, None) == 0
+        return 5
+
+    roots = ta.prover.fri_commit_phase_device(a, ea.data_ptr(), 64, 7, 1, 0, outer, la.data_ptr(), va.data_ptr())
+    assert len(roots) == 6 and seen["inner_rounds"] == 6     # 5 folds + the closing absorb, on B
+    reentrant = 10011
+    assert ta._lib.error_string(reentrant).startswith("entry point called on a context from inside")
+    assert seen["status"] and all(st == reentrant for _, st in seen["status"]), seen["status"]
+    assert try_a() == 0                                       # and A is free once its own phase has returned
+    torch.cuda.synchronize()
+    a.destroy(); b.destroy()

@@ -11,7 +11,7 @@ def t(fn, reps):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-for lg in (24, 27, 20):
+for lg in [int(v) for v in os.environ.get("XS_LOGS", "24,27,20").split(",")]:
     m = 1 << lg
     e = torch.randint(0, P, (m,), dtype=torch.int32, device=dev)
     xs = torch.randint(1, P, (m // 2,), dtype=torch.int32, device=dev)

@@ -51,6 +51,16 @@ with open(f"profiles/{tag}_fold_stats.csv", "w", newline="") as out:
                     f_[2] if f_ else "", w_[2] if w_ else "", (2 * f_[2] + w_[2]) * 1024 if f_ and w_ else ""])
 if os.path.exists(f"{src}/csrc_sha256.txt"):
     json.dump({"csrc_sha256": open(f"{src}/csrc_sha256.txt").read().strip()}, open(f"profiles/{tag}_fold_stats.meta.json", "w"))
+# explicit-point fold: VALU instructions per launch of the 2^24 layer (a counter instead of a hand count)
+xs = lambda name: "fri_fold_xs" in name  # noqa: E731
+xs_valu, xs_waves = counter_mean("fold_xs_valu", "SQ_INSTS_VALU", xs), counter_mean("fold_xs_valu", "SQ_WAVES", xs)
+if xs_valu:
+    obj = {"layer_log": 24, "kernels": {k: {"SQ_INSTS_VALU": v[0], "dispatches": v[1], "SQ_WAVES": xs_waves.get(k, (None,))[0],
+                                            "lane_ops_per_input_element": v[0] * 64.0 / (1 << 24)} for k, v in xs_valu.items()}}
+    if os.path.exists(f"{src}/csrc_sha256.txt"):
+        obj["csrc_sha256"] = open(f"{src}/csrc_sha256.txt").read().strip()
+    json.dump(obj, open(f"profiles/{tag}_counters_fold_xs.json", "w"), indent=1)
+    print(json.dumps(obj, indent=1))
 lat = stats_rows("latency_stats", lambda name: "ntt_pass" in name)
 with open(f"profiles/{tag}_latency_stats.csv", "w", newline="") as out:
     w = csv.writer(out)

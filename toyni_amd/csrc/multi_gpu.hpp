@@ -537,8 +537,12 @@ int slab_host_transform(const int* devices, int ndev, uint32_t n, uint64_t* h_da
 // real call -- same devices, same exchange kind -- and is compared with the SINGLE-device transform of the same input, forward and
 // back.  A wrong block order, a copy that raced its producer or a mis-declared RCCL signature shows up here as TOYNI_E_SELF_CHECK
 // instead of as a silently wrong proof.  Costs a few milliseconds once per (device list, exchange) and process.
-constexpr uint32_t SELF_CHECK_N = 1u << 18;
+// The probe must itself be a valid slab layout for the lane count (S1 / lanes >= 32 columns per lane, M1 >= lanes rows): 2^18 = 512 x
+// 512 serves up to 16 lanes, 2^22 (M1 = 128, S1 = 2^15) up to 128 (a fixed 2^18 probe answered E_RANGE for more than 16
+// lanes although the caller's own n was fine).  Only a VERDICT is cached -- ok, or a failed comparison; any other status (out of
+// memory, an RCCL start-up hiccup) is returned and the check runs again at the next call.
 int slab_self_check(const int* devices, int ndev, int exchange) {
+    const uint32_t SELF_CHECK_N = ndev <= 16 ? 1u << 18 : 1u << 22;
     if (ndev < 2) return TOYNI_OK;
     bool distinct = false;
     for (int a = 0; a < ndev; ++a) for (int b = a + 1; b < ndev; ++b) distinct |= devices[a] != devices[b];
@@ -569,9 +573,9 @@ int slab_self_check(const int* devices, int ndev, int exchange) {
     if (rc == TOYNI_OK) rc = slab_host_transform(devices, ndev, SELF_CHECK_N, got.data(), true, exchange);
     if (rc == TOYNI_OK && std::memcmp(x.data(), got.data(), n * sizeof(uint64_t)) != 0) rc = TOYNI_E_SELF_CHECK;
     if (verbose() || rc != TOYNI_OK)
-        std::fprintf(stderr, "toyni_hip: multi-device self-check (%d lanes, %s exchange, n = 2^18 against device %d alone): %s\n", ndev,
-                     exchange == TOYNI_EXCHANGE_RCCL ? "RCCL" : "peer-copy", devices[0], rc == TOYNI_OK ? "ok" : toyni_error_string(rc));
-    verdicts[key] = rc;
+        std::fprintf(stderr, "toyni_hip: multi-device self-check (%d lanes, %s exchange, n = 2^%d against device %d alone): %s\n", ndev,
+                     exchange == TOYNI_EXCHANGE_RCCL ? "RCCL" : "peer-copy", ilog2(SELF_CHECK_N), devices[0], rc == TOYNI_OK ? "ok" : toyni_error_string(rc));
+    if (rc == TOYNI_OK || rc == TOYNI_E_SELF_CHECK) verdicts[key] = rc;
     return rc;
 }
 

@@ -929,14 +929,25 @@ namespace {
 // The context whose transcript callback (toyni_fri_commit_phase_device) is running on THIS thread, if any.  The callback runs with
 // the context locked, so an entry point on the same context from inside it would deadlock on c->mu; it returns
 // TOYNI_E_REENTRANT instead (the rule was documented but not enforced).
-thread_local const toyni_ntt_ctx* t_callback_ctx = nullptr;
+// (round 4, ADVICE r3: a STACK, not one slot -- a callback of context A may run a commit phase on context B, whose own callbacks push
+// and pop B; A must still be refused afterwards.)
+thread_local std::vector<const toyni_ntt_ctx*> t_callback_ctxs;
+inline bool in_callback_of(const toyni_ntt_ctx* c) {
+    for (const toyni_ntt_ctx* x : t_callback_ctxs)
+        if (x == c) return true;
+    return false;
+}
+struct CallbackScope {
+    explicit CallbackScope(const toyni_ntt_ctx* c) { t_callback_ctxs.push_back(c); }
+    ~CallbackScope() { t_callback_ctxs.pop_back(); }
+};
 void finish_call(toyni_ntt_ctx* c);
 struct CtxCall {   // declared right after the lock: destroyed before it is released
     toyni_ntt_ctx* c;
     ~CtxCall() { finish_call(c); }
 };
 #define TOYNI_CTX_LOCK(c)                                   \
-    if (t_callback_ctx == (c)) return TOYNI_E_REENTRANT;   \
+    if (in_callback_of(c)) return TOYNI_E_REENTRANT;       \
     std::lock_guard<std::mutex> lk((c)->mu);               \
     CtxCall _ctx_call{(c)}
 
@@ -1075,6 +1086,15 @@ void finish_call(toyni_ntt_ctx* c) {
         if (r.ev && hipEventQuery(r.ev) == hipSuccess) { any_ready = true; break; }
     (void)hipGetLastError();   // hipErrorNotReady from the queries is not an error
     if (!any_ready) return;
+    // hipFree synchronises the device and is illegal while a global-mode capture is open.  Relaxed mode below covers THIS thread; a
+    // capture that another thread has open on one of this context's streams is visible here, and then the sweep waits for a later
+    // call.  What cannot be seen -- a global-mode capture on a stream this context has never carried -- is the caveat
+    // documented in include/toyni_hip.h: capture with hipStreamCaptureModeThreadLocal / Relaxed, or call toyni_ntt_ctx_trim first.
+    for (auto& kv : c->scratch) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(kv.first, &cap) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (cap != hipStreamCaptureStatusNone) return;
+    }
     hipStreamCaptureMode cmode = hipStreamCaptureModeRelaxed;
     (void)hipThreadExchangeStreamCaptureMode(&cmode);
     for (size_t i = 0; i < c->retired.size(); ++i) {
@@ -2299,9 +2319,11 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
     bool have_root = false;
     for (size_t m = m0; m > final_size; m >>= 1, ++round) {
         uint32_t beta = 0;
-        t_callback_ctx = c;
-        int rc = challenge(user, round, have_root ? c->h_root : nullptr, &beta);
-        t_callback_ctx = nullptr;
+        int rc;
+        {
+            CallbackScope scope(c);
+            rc = challenge(user, round, have_root ? c->h_root : nullptr, &beta);
+        }
         if (rc) return rc;
         if (beta >= BB_P) return TOYNI_E_RANGE;
         const size_t half = m >> 1;
@@ -2327,10 +2349,8 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
     if (rounds_out) *rounds_out = round;
     HIPCHK(hipStreamSynchronize(s));   // the call is blocking: the layers and trees are complete when it returns
     reclaim_after_sync(c, s);
-    t_callback_ctx = c;
-    const int rc_last = challenge(user, round, c->h_root, nullptr);   // the transcript absorbs the last commitment too, :242-243
-    t_callback_ctx = nullptr;
-    return rc_last;
+    CallbackScope scope(c);
+    return challenge(user, round, c->h_root, nullptr);   // the transcript absorbs the last commitment too, :242-243
 }
 
 static DomainArgs domain_args(toyni_ntt_ctx* c, unsigned log_m, uint32_t shift) {
