@@ -115,3 +115,35 @@ def test_random_low_degree_extensions_against_oracle(ta):
         for b in range(batch):
             want = oracle.domain_fft(coeffs[b * n_in:(b + 1) * n_in].astype(np.uint64), n, shift)
             assert (got[b * n:(b + 1) * n].astype(np.uint64) == want).all(), f"log_n={log_n} log_blowup={log_blowup} batch={batch} shift={shift} b={b}"
+
+
+def test_random_ext_shapes_against_oracle(ta):
+    """fft_ext / ifft_ext (src/math/domain.rs:129-151) through the interleaved passes: random sizes, vector counts, directions, coset
+    shifts, in place / out of place; every coordinate of every vector is the oracle's transform of that coordinate column."""
+    rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", str(0xE87)), 0))
+    budget = 1 << 21                      # Ext elements per case
+    for _ in range(int(os.environ.get("TOYNI_FUZZ_CASES", "70"))):
+        log_n = int(rng.integers(0, 20))
+        n = 1 << log_n
+        vecs = int(rng.integers(1, max(1, min(40, budget >> log_n)) + 1))
+        inverse = bool(rng.integers(0, 2))
+        shift = 1 if rng.integers(0, 3) else int(rng.integers(2, P))
+        inplace = bool(rng.integers(0, 2))
+        x = rng.integers(0, P, size=(vecs, n, 4), dtype=np.uint32)
+        ctx = ta.ntt.get_or_create_ctx(n)
+        a = DevBuf(ta, x.nbytes)
+        b = a if inplace else DevBuf(ta, x.nbytes)
+        try:
+            a.upload(x)
+            ctx.run_device_ext_batch(a.ptr, b.ptr, vecs, inverse, shift=shift)
+            ctx.synchronize()
+            got = b.download(np.uint32, x.size).reshape(x.shape)
+            if not inplace:
+                assert (a.download(np.uint32, x.size).reshape(x.shape) == x).all(), "out-of-place transform modified its input"
+        finally:
+            a.free()
+            if b is not a:
+                b.free()
+        for v in range(vecs):
+            want = _oracle_rows(np.ascontiguousarray(x[v].T), n, inverse, shift).reshape(4, n)
+            assert (got[v].T.astype(np.uint64) == want).all(), f"log_n={log_n} vecs={vecs} inverse={inverse} shift={shift} inplace={inplace} v={v}"

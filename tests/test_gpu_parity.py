@@ -425,6 +425,33 @@ def test_full_size_2_27_roundtrip(ta):
     assert (dev_transform(ta, fx, n, 1, True) == x).all()
 
 
+@pytest.mark.parametrize("log_n,vecs", [(24, 2), (27, 1)])
+def test_full_size_ext_vectors(ta, log_n, vecs):
+    """The interleaved (Ext, AoS) passes at the sizes no oracle run can afford: element offsets reach 2^29 words at n = 2^27 (the
+    limit of the 32-bit tile-relative byte offsets).  Every coordinate against the single-device BASE transform of that coordinate
+    (itself pinned at these sizes by the tests above), direct DFT spot checks, and the round trip."""
+    n = 1 << log_n
+    rng = np.random.default_rng(2700 + log_n)
+    x = rng.integers(0, P, size=(vecs, n, 4), dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, b = DevBuf(ta, x.nbytes), DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device_ext_batch(a.ptr, b.ptr, vecs, False)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size).reshape(vecs, n, 4)
+        ctx.run_device_ext_batch(b.ptr, b.ptr, vecs, True)
+        ctx.synchronize()
+        assert (b.download(np.uint32, x.size).reshape(x.shape) == x).all(), "round trip"
+    finally:
+        a.free(); b.free()
+    for v in range(vecs):
+        for k in range(4):
+            col = np.ascontiguousarray(x[v, :, k])
+            assert (y[v, :, k] == dev_transform(ta, col, n, 1, False)).all(), (v, k)
+    _spot_check_dft(np.ascontiguousarray(x[vecs - 1, :, 3]), np.ascontiguousarray(y[vecs - 1, :, 3]), n, [0, 1, 4097, n // 2, n - 1])
+
+
 def test_batch_1024_x_2_20(ta):
     # BASELINE configs[3] per-GPU shape: 1024 contiguous transforms of n = 2^20 (4 GiB packed)
     n, batch, block = 1 << 20, 1024, 32
