@@ -1158,17 +1158,6 @@ int lds_log_rows() {
     return v;
 }
 
-// prefetch variants (TOYNI_PREFETCH = 0 | 32: none / the whole next tile; tuning knob, 32 is the measured default).  Both are
-// kept instantiated for the plain kernels: with a single caller per pass shape the inliner makes different choices and the
-// 1024-point row pass ends up spilling (measured: 99 VGPRs / no scratch with both variants, 128 / 132 B scratch with one).
-int prefetch_depth() {
-    static const int depth = [] {
-        const char* env = std::getenv("TOYNI_PREFETCH");
-        return env ? std::atoi(env) : 32;
-    }();
-    return depth;
-}
-
 // prefetch depth of the interleaved (Ext) shapes: the prefetching kernel, except the single-pass 1024-point shape (32 virtual rows
 // per tile: with the next tile's 32 loads in flight it needs 128 VGPRs + 100 B of scratch; without them it fits)
 template <class P> constexpr int ext_prefetch() { return (kind_of<P>() == KIND_ROW_N && P::LM == 10) ? 0 : 32; }
@@ -1182,8 +1171,10 @@ void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntile
     } else if constexpr (P::LQ > 0) {  // interleaved (Ext) shapes: one kernel each (no A/B twin)
         hipLaunchKernelGGL((ntt_pass_kernel<P, ext_prefetch<P>()>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else {
-        if (prefetch_depth() == 0) hipLaunchKernelGGL((ntt_pass_kernel<P, 0>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
-        else hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        // (rounds 1-3 kept a no-prefetch twin of every shape instantiated: removing it once made the prefetching kernel spill.  With
+        // today's bodies it does not -- identical VGPR counts within one register, no scratch, and the same throughput in an alternating
+        // A/B at 2^14 ... 2^24, profiles/r04_ab_notwins.txt -- so the twins and their TOYNI_PREFETCH knob are gone: 55 kernels fewer)
+        hipLaunchKernelGGL((ntt_pass_kernel<P, 32>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     }
 }
 

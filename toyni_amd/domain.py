@@ -49,7 +49,7 @@ class BabyBearDomain:
         return values
 
     def fft_ext(self, coeffs4) -> np.ndarray:
-        """src/math/domain.rs:134-151: four base transforms, issued as ONE batch of 4."""
+        """src/math/domain.rs:134-151: the base transform of every coordinate -- the AoS vector goes through the interleaved passes as it is."""
         return self._transform_ext(coeffs4, inverse=False)
 
     def ifft_ext(self, evals4) -> np.ndarray:
@@ -61,7 +61,8 @@ class BabyBearDomain:
         ctx = _ntt.get_or_create_ctx(self.size)
         if not inverse:
             assert v.shape[0] <= self.size
-            # zero padding of :136-137 implied on the device; de-interleave / four transforms / recombine (:140-151) in one call
+            # zero padding of :136-137 implied on the device; the reference's de-interleave / four transforms / recombine (:140-151) is one call
+            # on the AoS vector (interleaved pass kernels: nothing is de-interleaved)
             return ctx.lde_ext_host(v, shift=self.shift)
         assert v.shape[0] == self.size
         vals = v.copy()
