@@ -96,6 +96,39 @@ static void test_domain_coset_fft_matches_horner() {
     EXPECT(threw, "the mirror has no CPU path");
 }
 
+// src/math/domain.rs:244-278: Ext FFT / IFFT round trip (n = 8, the reference's coefficients) and evaluation == Horner with
+// coordinate-wise mul_base at every base domain point (3 coefficients, zero padding implied) -- plus a coset domain of 2^12 points
+static void test_domain_ext_fft() {
+    if (!ntt::cuda_available()) return;
+    using toyni::Ext;
+    toyni::BabyBearDomain domain = toyni::BabyBearDomain(8).with_gpu(true);
+    std::vector<Ext> coeffs(8);
+    for (uint64_t i = 0; i < 8; ++i) coeffs[i] = Ext{{{orc_bb_new(i * 3 + 1)}, {orc_bb_new(i + 2)}, {orc_bb_new(i * 7)}, {orc_bb_new(i + 5)}}};
+    std::vector<Ext> evals = domain.fft_ext(coeffs);
+    std::vector<Ext> rec = domain.ifft_ext(evals);
+    for (size_t i = 0; i < 8; ++i)
+        for (int k = 0; k < 4; ++k) EXPECT(rec[i].c[k].value == coeffs[i].c[k].value, "Ext FFT/IFFT roundtrip failed at %zu.%d", i, k);
+    std::vector<Ext> three(3);
+    for (uint64_t i = 0; i < 3; ++i) three[i] = Ext{{{orc_bb_new(i + 1)}, {orc_bb_new(i * 2)}, {orc_bb_new(i + 4)}, {orc_bb_new(7)}}};
+    evals = domain.fft_ext(three);
+    std::vector<uint64_t> xs(8);
+    orc_domain_elements(xs.data(), 8, 1);
+    for (size_t i = 0; i < 8; ++i)
+        for (int k = 0; k < 4; ++k) {
+            uint64_t acc = 0;
+            for (int c = 2; c >= 0; --c) acc = orc_bb_add(orc_bb_mul(acc, xs[i]), three[c].c[k].value);   // acc.mul_base(x) + c, per coordinate
+            EXPECT(evals[i].c[k].value == acc, "Ext FFT eval mismatch at %zu.%d", i, k);
+        }
+    toyni::BabyBearDomain lde = toyni::BabyBearDomain(1 << 12).with_gpu(true).get_coset({7});
+    std::vector<Ext> poly(1 << 7);
+    for (size_t i = 0; i < poly.size(); ++i) for (int k = 0; k < 4; ++k) poly[i].c[k] = {orc_bb_new(i * 40503ull + 17 * k + 1)};
+    std::vector<Ext> back = lde.ifft_ext(lde.fft_ext(poly));
+    bool ok = true;
+    for (size_t i = 0; i < back.size(); ++i)
+        for (int k = 0; k < 4; ++k) ok = ok && back[i].c[k].value == (i < poly.size() ? poly[i].c[k].value : 0ull);
+    EXPECT(ok, "Ext coset LDE round trip");
+}
+
 // toyni_fri_commit_phase_device from compiled code: the fold loop of src/fibonacci.rs:222-245 with the transcript behind a C callback
 // (what a Rust prover binds as an `extern "C" fn` trampoline over its FiatShamirTranscript).  Layers vs orc_fri_fold on the squared
 // domain, trees vs orc_merkle_commit_values, and the callback must see exactly the committed roots, in order.
@@ -173,6 +206,7 @@ int main() {
     test_cuda_intt_roundtrip();
     test_buffer_and_fold();
     test_domain_coset_fft_matches_horner();
+    test_domain_ext_fft();
     test_commit_phase_callback();
     std::printf("%s\n", fails ? "CPP FAILED" : "CPP OK");
     return fails ? 1 : 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""sha256 over the library's sources (toyni_amd/csrc/**, include/*.h, sorted by path): the identity of the kernels a profile measured.
+"""sha256 over the library's sources (toyni_amd/csrc/* without csrc/host/, include/*.h, sorted by path): the identity of the kernels a profile measured.
 tools/collect_profiles.sh records it next to the counters ON THE BOX; bench.py compares it with the sources it is running from, so a
 profile quoted for roofline.traffic is either from exactly these kernels or flagged STALE -- no git needed (the box has no .git)."""
 import hashlib
@@ -12,7 +12,9 @@ def csrc_sha256():
     h = hashlib.sha256()
     files = []
     for base in ("toyni_amd/csrc", "include"):
-        for d, _, names in os.walk(os.path.join(ROOT, base)):
+        for d, dirs, names in os.walk(os.path.join(ROOT, base)):
+            if "host" in dirs:
+                dirs.remove("host")   # csrc/host/ = compiled-language CALLERS over the C ABI (C++ mirror, prover): not part of the library
             for n in names:
                 if n.endswith((".hip", ".hpp", ".h")):
                     files.append(os.path.relpath(os.path.join(d, n), ROOT))

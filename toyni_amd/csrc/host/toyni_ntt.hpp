@@ -20,6 +20,11 @@ struct BabyBear {
     uint64_t value;
 };
 static_assert(sizeof(BabyBear) == sizeof(uint64_t) && alignof(BabyBear) == alignof(uint64_t), "layout (src/ntt.rs:115-116)");
+// #[repr(C)] struct Ext { c: [BabyBear; 4] } = F_p[X]/(X^4 - 11)  (src/ext.rs): only the layout matters to the transforms
+struct Ext {
+    BabyBear c[4];
+};
+static_assert(sizeof(Ext) == 4 * sizeof(uint64_t), "Ext layout");
 
 // Ok(()) / Err(String)
 struct Result {
@@ -127,6 +132,25 @@ class BabyBearDomain {
         std::vector<BabyBear> values = evals;
         int st = toyni_coset_ntt_host(ctx, reinterpret_cast<uint64_t*>(values.data()), 1, shift_, 1);
         if (st != 0) throw std::runtime_error(std::string("GPU INTT failed: ") + toyni_error_string(st));
+        return values;
+    }
+
+    // fft_ext / ifft_ext (:129-151): the reference de-interleaves the four coordinates, transforms each and re-interleaves; here the
+    // AoS vector (Ext = #[repr(C)] [BabyBear; 4], src/ext.rs) goes through the interleaved passes as it is -- one ABI call each.
+    std::vector<Ext> fft_ext(const std::vector<Ext>& coeffs) const {
+        toyni_ntt_ctx* ctx = context();
+        std::vector<Ext> out(size_);
+        const size_t take = coeffs.size() < size_ ? coeffs.size() : size_;                               // `resize` truncates, :137
+        int st = toyni_lde_ext_host(ctx, reinterpret_cast<const uint64_t*>(coeffs.data()), take, reinterpret_cast<uint64_t*>(out.data()), shift_);
+        if (st != 0) throw std::runtime_error(std::string("GPU Ext NTT failed: ") + toyni_error_string(st));
+        return out;
+    }
+    std::vector<Ext> ifft_ext(const std::vector<Ext>& evals) const {
+        if (evals.size() != size_) throw std::logic_error("Evaluation count must match domain size");    // :130
+        toyni_ntt_ctx* ctx = context();
+        std::vector<Ext> values = evals;
+        int st = toyni_ntt_ext_host(ctx, reinterpret_cast<uint64_t*>(values.data()), shift_, 1);
+        if (st != 0) throw std::runtime_error(std::string("GPU Ext INTT failed: ") + toyni_error_string(st));
         return values;
     }
 
