@@ -129,8 +129,11 @@ def test_random_ext_shapes_against_oracle(ta):
         inverse = bool(rng.integers(0, 2))
         shift = 1 if rng.integers(0, 3) else int(rng.integers(2, P))
         inplace = bool(rng.integers(0, 2))
+        chunk = None if rng.integers(0, 4) else int(n * rng.integers(1, 4 * vecs + 1))   # in base-field elements: rounded up to whole vectors
         x = rng.integers(0, P, size=(vecs, n, 4), dtype=np.uint32)
         ctx = ta.ntt.get_or_create_ctx(n)
+        if chunk is not None:
+            ctx.set_chunk(chunk)
         a = DevBuf(ta, x.nbytes)
         b = a if inplace else DevBuf(ta, x.nbytes)
         try:
@@ -144,6 +147,7 @@ def test_random_ext_shapes_against_oracle(ta):
             a.free()
             if b is not a:
                 b.free()
+            ctx.set_chunk(0)
         for v in range(vecs):
             want = _oracle_rows(np.ascontiguousarray(x[v].T), n, inverse, shift).reshape(4, n)
-            assert (got[v].T.astype(np.uint64) == want).all(), f"log_n={log_n} vecs={vecs} inverse={inverse} shift={shift} inplace={inplace} v={v}"
+            assert (got[v].T.astype(np.uint64) == want).all(), f"log_n={log_n} vecs={vecs} inverse={inverse} shift={shift} inplace={inplace} chunk={chunk} v={v}"
