@@ -149,7 +149,7 @@ def multi_device_roofline(log_n, lanes, n_devices, step_s, phases_ms, exchange_k
         ex["note"] = "all lanes on ONE device: the exchange is device-local copies (a rehearsal of the control flow, not a link measurement)"
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * n_devices, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBPS * n_devices),
             "algorithmic_bytes_per_step": alg, "traffic": None,
-            "phases_ms_per_step": phases_ms, "phases_source": "HIP events on the launch stream between the stages of 3 extra steps after the timed region (rank 0)" if phases_ms else None,
+            "phases_ms_per_step": phases_ms, "phases_source": "HIP events on the launch stream between the stages of 3 extra steps after the timed region (rank 0 / lane 0)" if phases_ms else None,
             "exchange": ex}
 
 
@@ -353,6 +353,31 @@ def bench_slab_single_process(args):
         verified = all(torch.equal(rows[h].to(d0), nat[tdist.slab_output_index(log_n, lanes, h).to(d0).reshape(-1)]) for h in range(lanes))
         assert verified, "multi-device forward transform differs from the single-device transform"
         del nat
+    # where a step's time goes: three more steps through the measurement build of the same source, whose lane 0 carries an event
+    # between the four stages (toyni_tools_slab_phases; one-piece exchanges only)
+    phases = None
+    try:
+        import ctypes
+        tl = ctypes.CDLL(entry.build_tools())
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        tl.toyni_ntt_slab_multi_gpu_device.argtypes = [vp, ci, ctypes.c_uint32, vp, vp, ci, ci]
+        tl.toyni_tools_slab_phases_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
+        devs_c, slabs_c, rows_c = (ci * lanes)(*devices), (vp * lanes)(*sp), (vp * lanes)(*rp)
+        run = lambda inv: tl.toyni_ntt_slab_multi_gpu_device(devs_c, lanes, n, slabs_c, rows_c, inv, exchange)
+        before = [t.clone() for t in slabs]         # (the verification above left the forward pass's output in the slabs)
+        assert run(0) == 0 and run(1) == 0          # warm: this build's own contexts and buffers
+        assert tl.toyni_tools_slab_phases(1) == 0
+        psteps = 3
+        for _ in range(psteps):
+            assert run(0) == 0 and run(1) == 0
+        ms, cnt = (ctypes.c_float * 4)(), ctypes.c_uint(0)
+        assert tl.toyni_tools_slab_phases_read(ms, ctypes.byref(cnt)) == 0 and tl.toyni_tools_slab_phases(0) == 0
+        if cnt.value == 2 * psteps:
+            phases = {k: ms[i] / psteps for i, k in enumerate(("slab_pass", "exchange", "relayout", "row_transforms"))}
+        assert all(torch.equal(a, b) for a, b in zip(slabs, before)), "round trip through the measurement build changed the data"
+        del before
+    except (OSError, AttributeError) as exc:       # no measurement build: the line goes out without the per-phase times
+        print(f"bench.py: per-phase times unavailable ({exc})", file=sys.stderr)
     pci = {}
     for d in sorted(set(devices)):
         pr = torch.cuda.get_device_properties(d)
@@ -366,7 +391,7 @@ def bench_slab_single_process(args):
         "config": {"workload": f"forward+inverse slab-form NTT n=2^{log_n} (M1=2^{l1} x S1=2^{ls}) over {lanes} lane(s) on device(s) {sorted(set(devices))}, "
                                f"single process, exchange by {'RCCL grouped send/recv' if args.exchange == 'rccl' else 'hipMemcpyPeerAsync'}",
                    "log_n": log_n, "parallelism": f"column/row split x{lanes}, one exchange"},
-        "roofline": multi_device_roofline(log_n, lanes, len(set(devices)), wall / args.steps, None,
+        "roofline": multi_device_roofline(log_n, lanes, len(set(devices)), wall / args.steps, phases,
                                           "RCCL grouped send/recv" if args.exchange == "rccl" else "hipMemcpyPeerAsync, one copy stream per source"),
         "cpu_baseline": None if args.no_cpu_baseline else single_transform_cpu_baseline(log_n)}))
 

@@ -34,6 +34,11 @@ int toyni_ntt_ctx_timing_read(toyni_ntt_ctx* ctx, float* ms_sum, uint32_t* launc
 int toyni_tools_inject(unsigned flags);
 /* NCCL_VERSION_CODE reported by the librccl that dlopen found (0: not loadable / no ncclGetVersion). */
 int toyni_tools_rccl_version(void);
+/* Where a step of the single-process multi-device transform (toyni_ntt_slab_multi_gpu_*) spends its time: while enabled, lane 0's
+ * compute stream carries a HIP event between the four stages of every transform (one-piece exchanges only).  _read waits for them and
+ * adds up ms[0..3] = slab pass / exchange (the wait for the incoming blocks) / relayout / row transforms over *transforms transforms. */
+int toyni_tools_slab_phases(int enable);
+int toyni_tools_slab_phases_read(float* ms, unsigned* transforms);
 
 #ifdef __cplusplus
 }

@@ -101,5 +101,8 @@ def test_single_process_slab_line_carries_roofline_and_baseline():
     assert out["exchange_verified"] is True and out["lanes"] == 8
     roof, base = out["roofline"], out["cpu_baseline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    ph = roof["phases_ms_per_step"]                      # lane 0's stages from the measurement build's events
+    assert set(ph) == {"slab_pass", "exchange", "relayout", "row_transforms"} and all(v > 0 for v in ph.values())
+    assert sum(ph.values()) < 3 * out["ms_per_step"]     # one lane's stages: the same order of magnitude as a step (eight lanes share the device)
     assert roof["exchange"]["bytes_sent_per_rank_per_transform"] == 4 * (1 << 25) / 8 * 7 / 8 and "ONE device" in roof["exchange"]["note"]
     assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and base["extrapolated"] is True and "EXTRAPOLATED" in base["sample"]

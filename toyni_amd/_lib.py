@@ -146,6 +146,8 @@ TOOLS_SIGNATURES = {
     "toyni_ntt_profile_passes": (c_int, [c_void_p, c_void_p, c_size, c_int, c_int, ctypes.POINTER(ctypes.c_float), c_void_p]),
     "toyni_tools_inject": (c_int, [ctypes.c_uint]),
     "toyni_tools_rccl_version": (c_int, []),
+    "toyni_tools_slab_phases": (c_int, [c_int]),
+    "toyni_tools_slab_phases_read": (c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -309,6 +309,34 @@ int slab_exchange(SlabGroup* g, size_t blk, int exchange, SendPtr&& send, RecvPt
 // outgoing buffer d_xchg is piece-major: [K][G][rq][w].  K = TOYNI_SLAB_PIECES, default 1: with all eight lanes on ONE device there
 // is nothing to overlap and the extra launches and copies are pure host-side enqueue cost (2^27: 3.8 ms per forward + inverse at
 // K = 1, 5.9 at 4, 10.3 at 8); whether K > 1 pays on xGMI links has to be measured on a multi-GPU box.
+// Measurement build only (toyni_tools_slab_phases, include/toyni_hip_tools.h): HIP events on LANE 0's compute stream between the stages of a
+// transform -- slab pass / exchange (the time the stream waits for its incoming blocks) / relayout / row transforms -- so that
+// bench.py's single-process line can say where a step's time goes.  One-piece exchanges only.
+#ifdef TOYNI_TOOLS
+struct SlabPhaseRec {
+    std::mutex mu;
+    bool on = false;
+    struct Rec { hipEvent_t e[5]; bool inverse; };
+    std::vector<Rec> recs;
+    Rec cur{};
+    int device = 0;
+};
+inline SlabPhaseRec& slab_phase_rec() { static SlabPhaseRec r; return r; }
+inline void slab_phase_mark(SlabGroup* g, int k, bool inverse) {
+    SlabPhaseRec& pr = slab_phase_rec();
+    std::lock_guard<std::mutex> lk(pr.mu);
+    if (!pr.on) return;
+    SlabLane& L = g->lanes[0];
+    DeviceGuard guard(L.device);
+    if (k == 0) { pr.cur = SlabPhaseRec::Rec{}; pr.cur.inverse = inverse; pr.device = L.device; }
+    if (hipEventCreate(&pr.cur.e[k]) != hipSuccess || hipEventRecord(pr.cur.e[k], L.stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (k == 4) pr.recs.push_back(pr.cur);
+}
+#define MG_PHASE(g, k, inverse) slab_phase_mark((g), (k), (inverse))
+#else
+#define MG_PHASE(g, k, inverse) ((void)0)
+#endif
+
 size_t slab_pieces(size_t r) {
     static const size_t want = [] { const char* env = std::getenv("TOYNI_SLAB_PIECES"); const long v = env ? std::atol(env) : 1; return (size_t)(v < 1 ? 1 : v); }();
     size_t k = 1;
@@ -323,10 +351,13 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
         if (S.device == D.device) return (int)hipMemcpyAsync(dst, src, piece * sizeof(uint32_t), hipMemcpyDeviceToDevice, cs);
         return (int)hipMemcpyPeerAsync(dst, D.device, src, S.device, piece * sizeof(uint32_t), cs);
     };
+    const bool phases = K == 1;   // per-phase events (measurement build) make sense for the unpipelined exchange only
     if (!inverse) {
         for (size_t a = 0; a < G; ++a) {  // M1-point column transforms x w_n^(j' k1), in place on the slab; then "my blocks are final"
             SlabLane& L = g->lanes[a];
+            if (a == 0 && phases) MG_PHASE(g, 0, false);
             MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 0, L.stream));
+            if (a == 0 && phases) MG_PHASE(g, 1, false);
             DeviceGuard guard(L.device);
             MG_TRY(hipEventRecord(L.ready, L.stream));
         }
@@ -346,8 +377,11 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
             for (size_t h = 0; h < G; ++h) {  // piece q: pieces -> rows [rq][S1], then the size-S1 transforms over j'
                 SlabLane& L = g->lanes[h];
                 uint32_t* part = d_rows[h] + q * rq * g->s1;
+                if (h == 0 && phases) MG_PHASE(g, 2, false);   // behind the stream's waits for its incoming blocks: the exchange has landed
                 MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg + q * G * piece, part, rq, h * r + q * rq, G, 0, L.stream));
+                if (h == 0 && phases) MG_PHASE(g, 3, false);
                 MG_TRY(toyni_ntt_device(L.row, part, part, rq, 0, L.stream));
+                if (h == 0 && phases) MG_PHASE(g, 4, false);
             }
         }
     } else {
@@ -355,8 +389,11 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
             for (size_t h = 0; h < G; ++h) {  // inverse size-S1 transforms of piece q, then x w_n^-(k1 j') into outgoing pieces
                 SlabLane& L = g->lanes[h];
                 uint32_t* part = d_rows[h] + q * rq * g->s1;
+                if (h == 0 && phases) MG_PHASE(g, 0, true);
                 MG_TRY(toyni_ntt_device(L.row, part, part, rq, 1, L.stream));
+                if (h == 0 && phases) MG_PHASE(g, 1, true);
                 MG_TRY(toyni_ntt_slab_relayout_device(L.big, part, L.d_xchg + q * G * piece, rq, h * r + q * rq, G, 1, L.stream));
+                if (h == 0 && phases) MG_PHASE(g, 2, true);
                 DeviceGuard guard(L.device);
                 MG_TRY(hipEventRecord(L.ready, L.stream));   // re-recorded per piece: the waits below capture this recording
             }
@@ -377,7 +414,9 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
         }
         for (size_t a = 0; a < G; ++a) {
             SlabLane& L = g->lanes[a];
+            if (a == 0 && phases) MG_PHASE(g, 3, true);    // behind the waits for the incoming rows
             MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 1, L.stream));  // closing inverse column transforms, 1/M1
+            if (a == 0 && phases) MG_PHASE(g, 4, true);
         }
     }
     return TOYNI_OK;
@@ -392,25 +431,35 @@ int slab_run(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bo
     if (!inverse) {
         for (size_t a = 0; a < G; ++a) {  // M1-point column transforms x w_n^(j' k1), in place on the slab
             SlabLane& L = g->lanes[a];
+            if (a == 0) MG_PHASE(g, 0, false);
             MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 0, L.stream));
+            if (a == 0) MG_PHASE(g, 1, false);
         }
         // row block h of a slab (k1 in lane h's chunk) is contiguous: no packing
         MG_TRY(slab_exchange(g, blk, exchange, [&](size_t a) { return d_slabs[a]; }, [&](size_t h) { return g->lanes[h].d_xchg; }));
         for (size_t h = 0; h < G; ++h) {
             SlabLane& L = g->lanes[h];
+            if (h == 0) MG_PHASE(g, 2, false);   // the grouped send / recv run in stream order: behind them
             MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg, d_rows[h], r, h * r, G, 0, L.stream));  // pieces -> rows [r][S1]
+            if (h == 0) MG_PHASE(g, 3, false);
             MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 0, L.stream));                         // size-S1 transforms over j'
+            if (h == 0) MG_PHASE(g, 4, false);
         }
     } else {
         for (size_t h = 0; h < G; ++h) {
             SlabLane& L = g->lanes[h];
+            if (h == 0) MG_PHASE(g, 0, true);
             MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 1, L.stream));                         // inverse size-S1, scaled by 1/S1
+            if (h == 0) MG_PHASE(g, 1, true);
             MG_TRY(toyni_ntt_slab_relayout_device(L.big, d_rows[h], L.d_xchg, r, h * r, G, 1, L.stream));  // x w_n^-(k1 j'), rows -> pieces
+            if (h == 0) MG_PHASE(g, 2, true);
         }
         MG_TRY(slab_exchange(g, blk, exchange, [&](size_t h) { return g->lanes[h].d_xchg; }, [&](size_t a) { return d_slabs[a]; }));
         for (size_t a = 0; a < G; ++a) {
             SlabLane& L = g->lanes[a];
+            if (a == 0) MG_PHASE(g, 3, true);
             MG_TRY(toyni_ntt_slab_pass_device(L.big, d_slabs[a], w, a * w, 1, L.stream));  // closing inverse column transforms, 1/M1
+            if (a == 0) MG_PHASE(g, 4, true);
         }
     }
     return TOYNI_OK;
@@ -640,6 +689,37 @@ int toyni_ntt_slab_multi_gpu_host(const int* devices, int ndev, uint32_t n, uint
 #ifdef TOYNI_TOOLS  // include/toyni_hip_tools.h
 int toyni_tools_inject(unsigned flags) { g_inject.store(flags, std::memory_order_relaxed); return TOYNI_OK; }
 int toyni_tools_rccl_version(void) { return rccl().version; }
+
+int toyni_tools_slab_phases(int enable) {
+    SlabPhaseRec& pr = slab_phase_rec();
+    std::lock_guard<std::mutex> lk(pr.mu);
+    pr.on = enable != 0;
+    return TOYNI_OK;
+}
+// ms[0..3] = slab pass / exchange / relayout / row transforms, summed over the transforms recorded since the last read (forward and
+// inverse alike: the inverse runs the same four stages in the opposite order); *transforms = how many.  Waits for the events.
+int toyni_tools_slab_phases_read(float* ms, unsigned* transforms) {
+    if (!ms || !transforms) return TOYNI_E_NULL;
+    SlabPhaseRec& pr = slab_phase_rec();
+    std::lock_guard<std::mutex> lk(pr.mu);
+    for (int k = 0; k < 4; ++k) ms[k] = 0.f;
+    *transforms = 0;
+    DeviceGuard guard(pr.device);
+    hipError_t err = hipSuccess;
+    for (auto& r : pr.recs) {
+        hipError_t e = hipEventSynchronize(r.e[4]);
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventElapsedTime(&d[k], r.e[k], r.e[k + 1]);
+        if (e == hipSuccess) {
+            // forward: pass, exchange, relayout, rows; inverse: rows, relayout, exchange, pass
+            for (int k = 0; k < 4; ++k) ms[r.inverse ? 3 - k : k] += d[k];
+            *transforms += 1u;
+        } else if (err == hipSuccess) err = e;
+        for (int k = 0; k < 5; ++k) if (r.e[k]) (void)hipEventDestroy(r.e[k]);
+    }
+    pr.recs.clear();
+    return (int)err;
+}
 #endif
 
 }  // extern "C"
