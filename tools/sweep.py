@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the device-resident forward transform for every size 2^4 .. 2^27 at about 1 GiB of data per launch
 sequence (batch = 2^28 / n).  Prints one line per size: passes, ms, elements/s, actual GB/s moved (8 B/element/pass).
+SWEEP_EXT=1: the same data as Ext vectors through the interleaved passes.
 With the measurement build (TOYNI_LIB_OVERRIDE=toyni_amd/lib/libtoyni_hip_tools.so) and SWEEP_PASSES=1: each pass kernel's time."""
 import os
 import sys
@@ -26,7 +27,12 @@ def main():
         if batch * n > TOTAL:
             sys.exit(f"SWEEP_BATCH={batch} x n=2^{log_n} exceeds the {TOTAL}-element buffer of this tool")
         ctx = toyni_amd.NttContext(n)
-        f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
+        if os.environ.get("SWEEP_EXT"):    # the same bytes as Ext vectors (AoS, four interleaved coordinates): batch / 4 vectors
+            if batch < 4:
+                continue
+            f = lambda: ctx.run_device_ext_batch(ptr, ptr, batch // 4, False, stream=stream)  # noqa: E731
+        else:
+            f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
         for _ in range(3 if log_n > lo else 60):   # the first size also brings the chip out of its idle clocks
             f()
         torch.cuda.synchronize()

@@ -294,7 +294,17 @@ struct Pass {
         const uint32_t gamma = tid + g * T;
         if (KIND == KIND_ROW_N) {
             if (LQ_ == 0) { hi = gamma & (E1 - 1); c = gamma >> LE1; }
-            else { hi = (gamma >> LQ_) & (E1 - 1); c = ((gamma >> (LQ_ + LE1)) << LQ_) | (gamma & (Q - 1u)); }
+            else {
+                // A wave holds Q x 16 (q, hi) pairs.  Its store covers the output sub-indices bitrev(hi): with E1 = 32 the 16 consecutive
+                // hi of a wave would be every OTHER output element (16-byte chunks at a 32-byte stride, the rest of each line written by
+                // another wave at another time: measured 2.8 TB/s at n = 2^9).  Rotating the index left by one bit gives a wave the 16 hi
+                // of one parity = 16 CONSECUTIVE outputs x Q words = 256 contiguous bytes (at the price of a 2-way bank conflict on the
+                // step's LDS reads: the 16 even hi land on the even banks).
+                uint32_t h = (gamma >> LQ_) & (E1 - 1);
+                if (LE1 == 5) h = ((h << 1) | (h >> (LE1 - 1))) & (E1 - 1);
+                hi = h;
+                c = ((gamma >> (LQ_ + LE1)) << LQ_) | (gamma & (Q - 1u));
+            }
         }
         else { c = gamma & (C - 1); hi = gamma >> LC; }
     }
