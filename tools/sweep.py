@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the device-resident forward transform for every size 2^4 .. 2^27 at about 1 GiB of data per launch
 sequence (batch = 2^28 / n).  Prints one line per size: passes, ms, elements/s, actual GB/s moved (8 B/element/pass).
-SWEEP_EXT=1: the same data as Ext vectors through the interleaved passes.
+SWEEP_EXT=1: the same data as Ext vectors through the interleaved passes.  SWEEP_INVERSE=1, SWEEP_SHIFT=<coset shift>, SWEEP_LDE=<log2
+blow-up> (output elements are counted): the other forms of the same entry points.
 With the measurement build (TOYNI_LIB_OVERRIDE=toyni_amd/lib/libtoyni_hip_tools.so) and SWEEP_PASSES=1: each pass kernel's time."""
 import os
 import sys
@@ -19,6 +20,7 @@ def main():
     dev = torch.device("cuda", 0)
     data = torch.randint(0, P, (TOTAL,), dtype=torch.int32, device=dev)
     ptr = data.data_ptr()
+    out = torch.empty(TOTAL, dtype=torch.int32, device=dev) if os.environ.get("SWEEP_LDE") else None
     stream = torch.cuda.current_stream().cuda_stream
     lo, hi = (int(v) for v in os.environ.get("SWEEP_RANGE", "4:28").split(":"))
     for log_n in range(lo, hi):
@@ -27,12 +29,22 @@ def main():
         if batch * n > TOTAL:
             sys.exit(f"SWEEP_BATCH={batch} x n=2^{log_n} exceeds the {TOTAL}-element buffer of this tool")
         ctx = toyni_amd.NttContext(n)
-        if os.environ.get("SWEEP_EXT"):    # the same bytes as Ext vectors (AoS, four interleaved coordinates): batch / 4 vectors
+        inverse = bool(os.environ.get("SWEEP_INVERSE"))
+        shift = int(os.environ.get("SWEEP_SHIFT", "1"))          # coset shift (1 = plain)
+        lde = int(os.environ.get("SWEEP_LDE", "0"))              # > 0: low-degree extension by 2^lde (out of place, forward, into `out`)
+        if lde:
+            if lde > log_n or (os.environ.get("SWEEP_EXT") and batch < 4):
+                continue
+            if os.environ.get("SWEEP_EXT"):
+                f = lambda: ctx.lde_ext_device(ptr, out.data_ptr(), batch // 4, lde, shift, stream=stream)  # noqa: E731
+            else:
+                f = lambda: ctx.lde_device(ptr, out.data_ptr(), batch, lde, shift, stream=stream)  # noqa: E731
+        elif os.environ.get("SWEEP_EXT"):    # the same bytes as Ext vectors (AoS, four interleaved coordinates): batch / 4 vectors
             if batch < 4:
                 continue
-            f = lambda: ctx.run_device_ext_batch(ptr, ptr, batch // 4, False, stream=stream)  # noqa: E731
+            f = lambda: ctx.run_device_ext_batch(ptr, ptr, batch // 4, inverse, shift=shift, stream=stream)  # noqa: E731
         else:
-            f = lambda: ctx.run_device(ptr, ptr, batch, False, stream=stream)  # noqa: E731
+            f = lambda: ctx.run_device(ptr, ptr, batch, inverse, stream=stream, shift=shift)  # noqa: E731
         for _ in range(3 if log_n > lo else 60):   # the first size also brings the chip out of its idle clocks
             f()
         torch.cuda.synchronize()
