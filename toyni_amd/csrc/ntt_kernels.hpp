@@ -802,9 +802,15 @@ struct Pass {
 //   output sub-index of (a, b, d): k = rev(d) << (LE1+LE2) | rev(b) << LE1 | rev(a) = rev(d) << (LE1+LE2) | rev_{LE1+LE2}(hm)
 // LDS: KIND_COL word(c, r) = r C + c + (r >> LE3) PADC; KIND_ROW_T word(c, r) = c PITCH + r + (r >> LE3): every access of a
 // thread is one base register + a compile-time immediate; steps 1 and 2 are conflict-free, step 3 of the column kind too.
-template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false>
+// LQ_ = 2 (round 4): the interleaved (Ext, AoS) form, see Pass.  A 4-wide tile is then exactly ONE element's four coordinates: the
+// column kind needs only the twiddle column (column >> LQ); the row kind runs its four rows as the four coordinates q of one k_1
+// (row r of coordinate q at word 4 r + q: a wave's loads are 4-byte lanes at a 16-byte stride, the four waves of a row tile sharing
+// their lines -- these launches are cache-resident by construction -- and its stores the same 16-byte chunks as the base form's).
+template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false, int LQ_ = 0>
 struct Pass3 {
     static_assert(KIND == KIND_COL || KIND == KIND_ROW_T, "passes of multi-pass plans");
+    static_assert(LQ_ == 0 || (LQ_ == 2 && LC == 2), "interleaved latency tiles: one element's four coordinates");
+    static constexpr int LQ = LQ_;
     static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 4, "step sizes");
     static constexpr int STEPS = 3;
     static constexpr int LM = LE1 + LE2 + LE3, LLO = LE2 + LE3, LHM = LE1 + LE2;
@@ -856,21 +862,22 @@ struct Pass3 {
             t.col0 += a.col_base;
         } else {
             const uint32_t mid = bid & ((1u << a.log_mid) - 1);
-            const uint32_t k1_tiles_log = a.log_M1 - LC;
-            const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << LC;
+            const uint32_t k1_tiles_log = a.log_M1 - (LC - LQ_);
+            const uint32_t k1_0 = ((bid >> a.log_mid) & ((1u << k1_tiles_log) - 1)) << (LC - LQ_);
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
             t.row_shift = a.log_n - a.log_M1;
-            t.in = a.in + ((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM));
-            t.out = a.out + ((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1));
+            t.in = a.in + (((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM)) << LQ_);
+            t.out = a.out + (((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
             t.out0 = k1_0 + (mid << a.log_M1);
         }
         return t;
     }
+    // (interleaved row kind: c = (row << LQ) | q; linear in r / k, which is all the callers use)
     static TOYNI_HD uint32_t in_offset(const PassArgs& a, const Tile& t, uint32_t c, uint32_t r) {
-        return KIND == KIND_COL ? (r << a.log_S) + c : (c << t.row_shift) + r;
+        return KIND == KIND_COL ? (r << a.log_S) + c : ((((c >> LQ_) << t.row_shift) + r) << LQ_) + (c & ((1u << LQ_) - 1u));
     }
     static TOYNI_HD uint32_t out_offset(const PassArgs& a, uint32_t c, uint32_t k) {
-        return KIND == KIND_COL ? (k << a.log_S) + c : c + (k << (a.log_n - LM));
+        return KIND == KIND_COL ? (k << a.log_S) + c : c + (k << (a.log_n - LM + LQ_));
     }
 
     // thread coordinates: lanes run over what is contiguous in HBM (columns / the row) in step 1 and over the LDS-contiguous
@@ -908,7 +915,7 @@ struct Pass3 {
         if (KIND == KIND_COL && a.cs_mode == 1u) {
             uint32_t c, lo;
             coords1(tid, c, lo);
-            const uint32_t j0 = (lo << a.log_S) + t.col0 + c;
+            const uint32_t j0 = ((lo << a.log_S) + t.col0 + c) >> LQ_;
             r.lo = a.cs_lo[j0 & ((1u << a.cs_lowbits) - 1u)];
             r.hi = a.cs_hi[j0 >> a.cs_lowbits];
         }
@@ -978,7 +985,7 @@ struct Pass3 {
             coords3(tid, g, c, hm);
             const uint32_t khi = bitrev32(hm, LHM);
             if (KIND == KIND_COL) {
-                const uint32_t jcol = t.col0 + c;
+                const uint32_t jcol = (t.col0 + c) >> LQ_;
                 const uint32_t mask = (1u << a.tw_lowbits) - 1u;
                 const uint32_t ea = jcol * khi;
                 s.a_lo[g] = a.tw_lo[ea & mask];
@@ -989,7 +996,7 @@ struct Pass3 {
                     s.g_hi = a.tw_hi[eg >> a.tw_lowbits];
                 }
             } else if (a.cs_mode == 2u) {
-                const uint32_t e0 = t.out0 + c + (khi << (a.log_n - LM));
+                const uint32_t e0 = t.out0 + (c >> LQ_) + (khi << (a.log_n - LM));
                 s.a_lo[g] = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
                 s.a_hi[g] = a.cs_hi[e0 >> a.cs_lowbits];
             }

@@ -218,20 +218,24 @@ inline int& wide_min_log_tiles32() {
     return v;
 }
 
-// LQ > 0: the interleaved (Ext, AoS) variants -- two-step and single-step shapes only (a lone Ext transform is four transforms' worth
-// of tiles, the three-step latency shapes are not instantiated for it), tiles of at least 16 virtual rows / columns.
+// LQ > 0: the interleaved (Ext, AoS) variants: the same table (a lone Ext vector counts as four transforms' worth of tiles), without
+// the 8-wide two-step shapes and the 2048-point latency plans.
 template <int LQ = 0, class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
     // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
-    if (LQ == 0 && (log_m == 11 || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)))) {
-#define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { if constexpr (LQ == 0) f(Pass3<K, A, B, D, 2, false>{}); return true; }
-        TOYNI_PASS3_CASE(KIND_COL, 4, 4, 3)
-        TOYNI_PASS3_CASE(KIND_ROW_T, 4, 4, 3)
+    if ((LQ == 0 && log_m == 11) || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m))) {
+#define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false, LQ>{}); return true; }
+        if constexpr (LQ == 0) {   // 2048-point passes exist only in the base form's latency plans of n = 2^21 / 2^22
+            TOYNI_PASS3_CASE(KIND_COL, 4, 4, 3)
+            TOYNI_PASS3_CASE(KIND_ROW_T, 4, 4, 3)
+        }
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 2)
         TOYNI_PASS3_CASE(KIND_COL, 3, 3, 3)
-        TOYNI_PASS3_CASE(KIND_COL, 4, 3, 3)
+        if constexpr (LQ == 0) {   // (a 1024-point FIRST pass exists at n = 2^20 only, where even one Ext vector is 128 32-wide tiles: beyond the threshold)
+            TOYNI_PASS3_CASE(KIND_COL, 4, 3, 3)
+        }
         TOYNI_PASS3_CASE(KIND_ROW_T, 3, 3, 2)
         TOYNI_PASS3_CASE(KIND_ROW_T, 3, 3, 3)
         TOYNI_PASS3_CASE(KIND_ROW_T, 4, 3, 3)
@@ -316,9 +320,11 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
 #define TOYNI_COMMA ,
     if constexpr (LQ == 0) {
         if (log_m == 11) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
-        if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
-            if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2>) }
-            if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
+    }
+    if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {
+        if (log_m == 8) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA 2 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+        if (log_m == 9) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2 TOYNI_COMMA false TOYNI_COMMA LQ>) }
+        if constexpr (LQ == 0) {
             if (log_m == 10) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
         }
     }
