@@ -250,10 +250,7 @@ static void test_fold(int log_N, int layer, uint32_t shift) {
     FoldArgs f{};
     f.evals = e32.data();
     f.out = out.data();
-    f.inv_lo = plan.inv.data() + plan.dom_lo_off;
-    f.inv_hi = plan.inv.data() + plan.dom_hi_off;
-    f.lowbits = plan.dom_lowbits;
-    f.log_step = (uint32_t)layer;
+    f.dom = sub_domain(plan, plan.inv.data(), layer);
     const uint32_t x0 = (uint32_t)xs[0];
     f.coef = to_mont_host(bb_mul_host(bb_mul_host((uint32_t)beta, BB_HALF), bb_inv_host(x0)));
     f.half = half;
@@ -480,10 +477,7 @@ static void test_slab(int log_n, uint64_t G) {
 // Pointwise prover steps (prover_kernels.hpp) against the oracle's restatement of src/fibonacci.rs:133-150,186-198
 static DomainArgs emu_domain(const NttPlan& plan, int log_m, uint32_t shift) {
     DomainArgs d{};
-    d.lo = plan.fwd.data() + plan.dom_lo_off;
-    d.hi = plan.fwd.data() + plan.dom_hi_off;
-    d.lowbits = plan.dom_lowbits;
-    d.log_step = (uint32_t)(plan.log_n - log_m);
+    d.dom = sub_domain(plan, plan.fwd.data(), plan.log_n - log_m);
     d.shiftR = to_mont_host(shift);
     return d;
 }

@@ -33,6 +33,8 @@ struct NttPlan {
     PassPlan pass[MAX_PASSES];
     // domain table: two-level w_n^x (fwd blob) / w_n^-x (inv blob), x < n
     uint32_t dom_lo_off = 0, dom_hi_off = 0, dom_lowbits = 0;
+    // compact low levels of its subgroups (SubDomain, ntt_kernels.hpp): dom_sub_off[s] -> w^(x << s), x < 2^(dom_lowbits - s), 0 < s < dom_lowbits
+    uint32_t dom_sub_off[32] = {};
     uint32_t scale_inv = 0;             // Montgomery form of n^-1, applied by the first pass of an inverse transform
     // n = 2^11 .. 2^15: tables of the single-sweep LDS-resident kernel (LdsPass<lds_la>); lds_la = 0 otherwise
     int lds_la = 0;
@@ -171,8 +173,28 @@ inline bool build_plan(int log_n, NttPlan& plan, bool latency = false) {
         // domain table w_n^(+-x), x < n: the FRI fold reads the inverse one (x_i^-1 = x0^-1 * w_n^-i), the
         // multi-GPU 4-step transform both (same offsets in both blobs)
         append_two_level(blob, log_n, w, 1u, plan.dom_lo_off, plan.dom_hi_off, plan.dom_lowbits);
+        for (uint32_t s = 1; s < plan.dom_lowbits; ++s) {   // the subgroups' compact low levels: 2^dom_lowbits words in all
+            plan.dom_sub_off[s] = (uint32_t)blob.size();
+            const uint32_t ws = bb_pow_host(w, 1ull << s);
+            uint32_t cur = 1;
+            for (uint32_t x = 0; x < (1u << (plan.dom_lowbits - s)); ++x) {
+                blob.push_back(to_mont_host(cur));
+                cur = bb_mul_host(cur, ws);
+            }
+        }
     }
     return true;
+}
+
+// the order-(n >> s) subgroup inside the plan's domain table, on the blob at `tables` (fwd or inv; host or device copy)
+inline SubDomain sub_domain(const NttPlan& plan, const uint32_t* tables, int s) {
+    const uint32_t L = plan.dom_lowbits;
+    SubDomain d{};
+    d.hi = tables + plan.dom_hi_off;
+    if (s <= 0) { d.lo = tables + plan.dom_lo_off; d.lo_mask = (1u << L) - 1u; d.rsh = L; d.lsh = 0; }
+    else if ((uint32_t)s < L) { d.lo = tables + plan.dom_sub_off[s]; d.lo_mask = (1u << (L - (uint32_t)s)) - 1u; d.rsh = L - (uint32_t)s; d.lsh = 0; }
+    else { d.lo = tables + plan.dom_lo_off; d.lo_mask = 0; d.rsh = 0; d.lsh = (uint32_t)s - L; }   // lo[0] = 1
+    return d;
 }
 
 // (kind, log_m) -> Pass<...> instantiation.  This table is the single place that fixes the step split and

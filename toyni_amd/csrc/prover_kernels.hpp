@@ -18,16 +18,11 @@ namespace toyni {
 
 // x_i = shift * w_N^i from the context's forward two-level domain table; returned in MONTGOMERY form (x_i * R)
 struct DomainArgs {
-    const uint32_t* lo;   // w_N^x, x < 2^lowbits           (Montgomery)
-    const uint32_t* hi;   // w_N^(y << lowbits)              (Montgomery)
-    uint32_t lowbits;
-    uint32_t log_step;    // table root is w_{N'} with N' = N << log_step
+    SubDomain dom;        // w_N'^(i << s): the order-N subgroup inside the context's (possibly larger) forward domain table (ntt_kernels.hpp)
     uint32_t shiftR;      // Montgomery form of the coset shift
 };
 TOYNI_HD uint32_t domain_point_mont(const DomainArgs& d, uint64_t i) {
-    const uint32_t e = (uint32_t)(i << d.log_step);
-    const uint32_t w = mont_mul(d.hi[e >> d.lowbits], d.lo[e & ((1u << d.lowbits) - 1u)]);  // w^e * R
-    return mont_mul(w, d.shiftR);                                                             // shift * w^e * R
+    return mont_mul(subdomain_mont(d.dom, (uint32_t)i), d.shiftR);   // shift * w^i * R
 }
 
 // a^-1 in Montgomery form (aR -> a^-1 R) by Fermat, as BabyBear::inverse (src/babybear.rs:111-114); 0 -> 0

@@ -294,14 +294,11 @@ __global__ void __launch_bounds__(256) slab_relayout_kernel(const RelayoutArgs a
 
 // roots_of_unity_domain / BabyBearDomain::elements (src/ntt.rs:69-81, src/math/domain.rs:61-69): out[i] = shift * w_m^i, the
 // reference's serial multiply chain as independent two-level table lookups (w_m^i = w_n^(i << log_step), forward domain table)
-__global__ void __launch_bounds__(256) domain_elements_kernel(uint32_t* __restrict__ out, uint64_t m, uint32_t log_step, uint32_t shift,
-                                                               const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t lowbits) {
+__global__ void __launch_bounds__(256) domain_elements_kernel(uint32_t* __restrict__ out, uint64_t m, uint32_t shift, const SubDomain dom) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lmask = (1u << lowbits) - 1u;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        const uint32_t e = (uint32_t)(i << log_step);
-        // mont_mul(hi, lo) = Montgomery form of w^e; times the PLAIN shift leaves the plain product shift * w^e
-        out[i] = mont_mul(mont_mul(hi[e >> lowbits], lo[e & lmask]), shift);
+        // subdomain_mont = Montgomery form of w_m^i; times the PLAIN shift leaves the plain product shift * w_m^i
+        out[i] = mont_mul(subdomain_mont(dom, (uint32_t)i), shift);
     }
 }
 
@@ -639,9 +636,7 @@ __global__ void __launch_bounds__(256) fri_fold_ext_kernel(const FoldExtArgs fa)
     const uint4* eb = ea + half;
     uint4* o = reinterpret_cast<uint4*>(f.out);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += stride) {
-        const uint32_t e = (uint32_t)(i << f.log_step);
-        const uint32_t w = mont_mul(f.inv_hi[e >> f.lowbits], f.inv_lo[e & ((1u << f.lowbits) - 1)]);
-        const uint32_t scaleR = mont_mul(w, f.coef);
+        const uint32_t scaleR = mont_mul(subdomain_mont(f.dom, (uint32_t)i), f.coef);
         const uint4 a = ea[i], b = eb[i];
         const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, scaleR, fa.beta_half);
         o[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
@@ -679,9 +674,7 @@ __global__ void __launch_bounds__(T) fri_fold_ext_stream_kernel(const FoldExtArg
         for (int u = 0; u < U; ++u) {
             const uint64_t i = c0 + (uint64_t)u * T + threadIdx.x;
             if (i < half) {
-                const uint32_t e = (uint32_t)(i << f.log_step);
-                const uint32_t w = mont_mul(f.inv_hi[e >> f.lowbits], f.inv_lo[e & ((1u << f.lowbits) - 1)]);
-                const uint32_t scaleR = mont_mul(w, f.coef);
+                const uint32_t scaleR = mont_mul(subdomain_mont(f.dom, (uint32_t)i), f.coef);
                 const Ext4 r = fold_ext_one(Ext4{{a[u].x, a[u].y, a[u].z, a[u].w}}, Ext4{{b[u].x, b[u].y, b[u].z, b[u].w}}, scaleR, fa.beta_half);
                 if constexpr (NT) {
                     u32x4 vr = {r.c[0], r.c[1], r.c[2], r.c[3]};
@@ -1930,13 +1923,24 @@ int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, ui
     if (!is_pow2(m) || m > c->n || shift >= BB_P) return TOYNI_E_RANGE;
     TOYNI_CTX_LOCK(c);
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(domain_elements_kernel, dim3(grid_for(m)), dim3(256), 0, (hipStream_t)stream, d_out, (uint64_t)m,
-                       (uint32_t)(c->plan.log_n - ilog2(m)), shift, c->d_fwd + c->plan.dom_lo_off, c->d_fwd + c->plan.dom_hi_off,
-                       c->plan.dom_lowbits);
+    hipLaunchKernelGGL(domain_elements_kernel, dim3(grid_for(m)), dim3(256), 0, (hipStream_t)stream, d_out, (uint64_t)m, shift,
+                       sub_domain(c->plan, c->d_fwd, c->plan.log_n - ilog2(m)));
     return (int)hipGetLastError();
 }
 
 // ---- FRI fold ----
+// input bytes from which a fold streams past the caches: the shaped-stream kernels with non-temporal accesses.  256 MiB = the Infinity
+// Cache (TOYNI_FOLD_NT_MIN_BYTES; the transforms' gate, TOYNI_NT_MIN_BYTES, is 512 MiB).  Measured with tools/foldsweep.py, gate at 512 /
+// 256 / 128 MiB: structured 2^26 layer (256 MiB in) 76.1 / 67.2 / 67.6 us, Ext 2^24 layer (256 MiB in) 77.5 / 68.2 / 68.7 us -- and at
+// 128 MiB the layers that still fit the cache lose (structured 2^25: 33.7 -> 38.2 us, Ext 2^23: 31.2 -> 35.6).
+static uint64_t fold_nt_min_bytes() {
+    static const uint64_t v = [] {
+        const char* env = std::getenv("TOYNI_FOLD_NT_MIN_BYTES");
+        return env ? (uint64_t)std::strtoull(env, nullptr, 0) : (uint64_t)256 << 20;
+    }();
+    return v;
+}
+
 static int fold_shape() {
     static const int v = [] { const char* e = std::getenv("TOYNI_FOLD_SHAPE"); return e ? std::atoi(e) : 2; }();
     return v;
@@ -1949,10 +1953,7 @@ static int fold_args(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out,
     f = FoldArgs{};
     f.evals = d_evals;
     f.out = d_out;
-    f.inv_lo = c->d_inv + c->plan.dom_lo_off;
-    f.inv_hi = c->d_inv + c->plan.dom_hi_off;
-    f.lowbits = c->plan.dom_lowbits;
-    f.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
+    f.dom = sub_domain(c->plan, c->d_inv, c->plan.log_n - ilog2(m));
     f.coef = to_mont_host(bb_mul_host(bb_mul_host(beta, BB_HALF), bb_inv_host(x0)));
     f.half = m / 2;
     f.step = to_mont_host(bb_inv_host(bb_root_of_unity_host((uint32_t)ilog2(m))));
@@ -1971,19 +1972,18 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     if (d_leaves) {
         hipLaunchKernelGGL((fri_fold_kernel<false, true>), dim3(grid_for(work)), dim3(256), 0, s, f, reinterpret_cast<const uint4*>(d_salts),
                            reinterpret_cast<Digest*>(d_leaves));
-    } else if ((f.half & 3) == 0 && m >= ((uint64_t)1 << 26) && fold_shape() != 0) {
-        // (layers of >= 256 MiB: measured +22 % at 2^26 and +10 % at 2^27 elements; a cache-resident 2^24 layer is 5 % FASTER on the
-        // 256-thread kernel below -- 5.95 against 5.63 TB/s -- so smaller layers keep it)
-        // large layers: the shaped stream, 1024 threads x 2 load pairs in flight.  TOYNI_FOLD_SHAPE=0 (A/B knob): round 2's kernel.
-        // Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for the round-2 kernel, 5.83 for its
-        // shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4 -- only the winner is instantiated.
-        const bool nt = (uint64_t)m * sizeof(uint32_t) >= nt_min_bytes();
+    } else if ((f.half & 3) == 0 && m >= 64 && (uint64_t)m * sizeof(uint32_t) >= fold_nt_min_bytes() && fold_shape() != 0) {
+        // layers beyond the Infinity Cache (>= 256 MiB of input): the shaped stream, 1024 threads x 2 load pairs in flight, non-temporal.
+        // A cache-resident 2^24 layer is 5 % FASTER on the 256-thread kernel below (5.95 against 5.63 TB/s), so smaller layers keep it.
+        // TOYNI_FOLD_SHAPE=0 (A/B knob): round 2's kernel.  Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt):
+        // 5.45-5.47 TB/s for the round-2 kernel, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 /
+        // 1024 x 2 / 512 x 4 -- only the winner is instantiated.  (Round 4: the gate was 2^26 elements with the non-temporal hint from
+        // 512 MiB only, so a 2^26 layer streamed with plain accesses: 76 -> 67 us with the hint, tools/foldsweep.py.)
         const uint64_t quads = f.half / 4, chunk = 1024 * 2, cap = (uint64_t)c->num_cus * 8;
         uint64_t g = (quads + chunk - 1) / chunk;
         if (g > cap) g = cap;
-        if (nt) hipLaunchKernelGGL((fri_fold_stream_kernel<true, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
-        else hipLaunchKernelGGL((fri_fold_stream_kernel<false, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
-    } else if ((uint64_t)m * sizeof(uint32_t) >= nt_min_bytes()) {
+        hipLaunchKernelGGL((fri_fold_stream_kernel<true, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
+    } else if ((uint64_t)m * sizeof(uint32_t) >= fold_nt_min_bytes()) {
         hipLaunchKernelGGL((fri_fold_kernel<true, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     } else {
         hipLaunchKernelGGL((fri_fold_kernel<false, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
@@ -2076,15 +2076,13 @@ int toyni_fri_fold_ext_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_
     DeviceGuard guard(c->device);
     fa.base.evals = d_evals;
     fa.base.out = d_out;
-    fa.base.inv_lo = c->d_inv + c->plan.dom_lo_off;
-    fa.base.inv_hi = c->d_inv + c->plan.dom_hi_off;
-    fa.base.lowbits = c->plan.dom_lowbits;
-    fa.base.log_step = (uint32_t)(c->plan.log_n - ilog2(m));
+    fa.base.dom = sub_domain(c->plan, c->d_inv, c->plan.log_n - ilog2(m));
     fa.base.coef = to_mont_host(bb_inv_host(x0));
     fa.base.half = m / 2;
-    // streaming layers (>= TOYNI_NT_MIN_BYTES = 512 MiB of input): the shaped stream, 5.0-5.2 -> 6.0 TB/s on a 2^25-element layer; a
-    // cache-resident 2^22-element layer is faster on the 256-thread kernel (6.2 against 4.8 TB/s: profiles/r03_ab_fold_ext_shape.txt)
-    if ((uint64_t)m * 16 >= nt_min_bytes() && fold_shape() != 0) {
+    // streaming layers (>= TOYNI_FOLD_NT_MIN_BYTES = 256 MiB of input): the shaped stream, 5.0-5.2 -> 6.0 TB/s on a 2^25-element layer,
+    // 5.2 -> 5.9 on a 2^24-element one (256 MiB in, 128 MiB out: past the Infinity Cache); a cache-resident 2^22-element layer is faster
+    // on the 256-thread kernel (6.2 against 4.8 TB/s: profiles/r03_ab_fold_ext_shape.txt)
+    if ((uint64_t)m * 16 >= fold_nt_min_bytes() && fold_shape() != 0) {
         const uint64_t chunk = 2 * 1024, cap = (uint64_t)c->num_cus * 8;
         uint64_t g = (fa.base.half + chunk - 1) / chunk;
         if (g > cap) g = cap;
@@ -2346,10 +2344,7 @@ int toyni_fri_commit_phase_device(toyni_ntt_ctx* c, const uint32_t* d_layer0, si
 
 static DomainArgs domain_args(toyni_ntt_ctx* c, unsigned log_m, uint32_t shift) {
     DomainArgs d{};
-    d.lo = c->d_fwd + c->plan.dom_lo_off;
-    d.hi = c->d_fwd + c->plan.dom_hi_off;
-    d.lowbits = c->plan.dom_lowbits;
-    d.log_step = (uint32_t)(c->plan.log_n - (int)log_m);
+    d.dom = sub_domain(c->plan, c->d_fwd, c->plan.log_n - (int)log_m);
     d.shiftR = to_mont_host(shift);
     return d;
 }
