@@ -14,6 +14,6 @@ def t(fn, reps):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-for m in (1 << 27, 1 << 26):
+for m in [1 << int(v) for v in os.environ.get("FOLD_LOGS", "27,26").split(",")]:
     ms = t(lambda: toyni_amd.fri_fold_device(c27, big.data_ptr(), o2.data_ptr(), m, 123456789, 7, stream=stream), 30)
     print(f"fold m=2^{m.bit_length()-1}: {ms*1e3:.1f} us  {6.0*m/ms/1e6:.0f} GB/s")
