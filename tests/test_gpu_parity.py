@@ -772,6 +772,12 @@ def test_lde_host_is_domain_fft(ta, log_n, ncoeffs):
     if ncoeffs:                                      # non-canonical u64 inputs behave like BabyBear::new (src/babybear.rs:26-30)
         big = coeffs + np.uint64(P) * np.uint64(3)
         assert (ta.ntt.get_or_create_ctx(n).lde_host(big, shift=7) == want).all()
+        reuse = np.full(n, 0xdead, dtype=np.uint64)  # the caller's own output array, reused
+        assert ta.ntt.get_or_create_ctx(n).lde_host(coeffs, shift=7, out=reuse) is reuse and (reuse == want).all()
+        if n >= 2:
+            xs = oracle.domain_elements(n, 7)[: n // 2]
+            half = np.empty(n // 2, dtype=np.uint64)
+            assert ta.fri_fold(want, xs, 99, out=half) is half and (half == oracle.fri_fold(want, xs, 99)).all()
 
 
 @pytest.mark.parametrize("log_n,ncoeffs", [(0, 1), (4, 5), (10, 0), (10, 1000), (12, 64), (16, 3000), (20, 1 << 15), (21, 1 << 21)])

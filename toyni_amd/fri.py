@@ -5,13 +5,15 @@ import numpy as np
 from ._lib import check, lib
 
 
-def fri_fold(evals, xs, beta: int) -> np.ndarray:
-    """src/math/fri.rs:27-48: host slices (u64 elements) in, new array of len/2 out."""
+def fri_fold(evals, xs, beta: int, out: np.ndarray = None) -> np.ndarray:
+    """src/math/fri.rs:27-48: host slices (u64 elements) in, new array of len/2 out (or `out`, len/2 contiguous u64, reused)."""
     e = np.ascontiguousarray(evals, dtype=np.uint64)
     x = np.ascontiguousarray(xs, dtype=np.uint64)
     assert e.size % 2 == 0, "Evaluations length must be even"  # src/math/fri.rs:28
     assert x.size >= e.size // 2
-    out = np.empty(e.size // 2, dtype=np.uint64)
+    if out is None:
+        out = np.empty(e.size // 2, dtype=np.uint64)
+    assert out.dtype == np.uint64 and out.size == e.size // 2 and out.flags.c_contiguous, "out: len/2 contiguous u64"
     st = lib.toyni_fri_fold_host(out.ctypes.data, e.ctypes.data, e.size, x.ctypes.data, int(beta))
     assert st != 10005, "Cannot invert zero"  # src/babybear.rs:112
     check(st, "GPU FRI fold failed")

@@ -145,10 +145,14 @@ class NttContext:
         """Low-degree extension: forward coset transform of batch vectors of n >> log_blowup coefficients, zero padding implied."""
         check(lib.toyni_lde_device(self.handle, d_coeffs, d_out, batch, log_blowup, shift, stream or None), "GPU LDE failed")
 
-    def lde_host(self, coeffs: np.ndarray, shift: int = 1) -> np.ndarray:
-        """BabyBearDomain::fft(coeffs) in one call: len(coeffs) <= n coefficients up, n evaluations on shift * <w_n> back."""
+    def lde_host(self, coeffs: np.ndarray, shift: int = 1, out: np.ndarray = None) -> np.ndarray:
+        """BabyBearDomain::fft(coeffs) in one call: len(coeffs) <= n coefficients up, n evaluations on shift * <w_n> back.
+        `out` (optional, n contiguous u64) is reused instead of a fresh array: from 32 MiB up the allocator hands out fresh
+        mmap'ed pages per call and their first-touch faults during the download cost more than the call itself."""
         c = np.ascontiguousarray(coeffs, dtype=np.uint64)
-        out = np.empty(self.n, dtype=np.uint64)
+        if out is None:
+            out = np.empty(self.n, dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.size == self.n and out.flags.c_contiguous, "out: n contiguous u64"
         check(lib.toyni_lde_host(self.handle, c.ctypes.data if c.size else None, c.size, out.ctypes.data, shift), "GPU LDE failed")
         return out
 
