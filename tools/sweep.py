@@ -48,16 +48,25 @@ def main():
         for _ in range(3 if log_n > lo else 60):   # the first size also brings the chip out of its idle clocks
             f()
         torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10 if batch > 1 else 200
-        a.record()
-        for _ in range(reps):
-            f()
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
-        print(f"n=2^{log_n:<2d} batch={batch:<9d} passes={ctx.passes} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
-              f"{8.0 * ctx.passes * batch * n / ms / 1e9:7.2f} TB/s moved", flush=True)
+        windows = []
+        for _ in range(5):   # five windows of `reps` calls: the median (single windows differ by up to 15 % from box to box at 2^18 / 2^19)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                f()
+            b.record()
+            torch.cuda.synchronize()
+            windows.append(a.elapsed_time(b) / reps)
+        ms = sorted(windows)[2]
+        spread = (max(windows) - min(windows)) / ms
+        # the launcher's rule (toyni_hip.hip: use_lds_kernel, default knobs): plain base transforms of 2^11 .. 2^13 in launches of >= 2^25
+        # elements run the single-sweep LDS kernel instead of the plan's two passes
+        lds = (11 <= log_n <= int(os.environ.get("TOYNI_LDS_MAX_LOG", "13")) and batch * n >= int(os.environ.get("TOYNI_LDS_MIN_ELEMS", 1 << 25))
+               and not lde and not os.environ.get("SWEEP_EXT"))
+        sweeps = 1 if lds else ctx.passes
+        print(f"n=2^{log_n:<2d} batch={batch:<9d} sweeps={sweeps} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
+              f"{8.0 * sweeps * batch * n / ms / 1e9:7.2f} TB/s moved  (windows +-{50 * spread:.1f} %)", flush=True)
         if toyni_amd._lib.HAS_TOOLS and os.environ.get("SWEEP_PASSES"):   # TOYNI_LIB_OVERRIDE=.../libtoyni_hip_tools.so
             per = ctx.profile_passes(ptr, batch, False, reps=5, stream=stream)
             print("      per pass: " + "  ".join(f"{t:.4f} ms ({8.0 * batch * n / t / 1e9:.2f} TB/s)" for t in per), flush=True)
