@@ -54,3 +54,32 @@ def test_batch_of_more_than_2_32_elements(ta, log_n, batch):
         ctx.destroy()
         del data, keep
         torch.cuda.empty_cache()
+
+
+def test_out_of_device_memory_is_a_status_and_the_context_survives(ta):
+    # the intermediate buffer of a multi-pass transform is as large as the data: when the device cannot hold it the call returns
+    # hipErrorOutOfMemory (2) before any kernel ran, and the same context works once the memory is back
+    from toyni_amd._lib import lib
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, batch = 1 << 20, 512                                   # 2 GiB of data, 2 GiB of intermediates
+    data = fill(batch * n, dev, 77)
+    keep = data.clone()
+    ctx = ta.NttContext(n)
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (1 << 30), dtype=torch.uint8, device=dev)   # 1 GiB left
+    try:
+        st = lib.toyni_ntt_device(ctx.handle, data.data_ptr(), data.data_ptr(), batch, 0, stream)
+        torch.cuda.synchronize()
+        assert st == 2 and b"memory" in lib.toyni_error_string(st)
+        assert torch.equal(data, keep), "a refused call must not have touched the data"
+        del hog
+        torch.cuda.empty_cache()
+        assert lib.toyni_ntt_device(ctx.handle, data.data_ptr(), data.data_ptr(), batch, 0, stream) == 0
+        torch.cuda.synchronize()
+        for b in (0, batch - 1):
+            want = oracle.ntt(keep[b * n:(b + 1) * n].cpu().numpy().view(np.uint32).astype(np.uint64))
+            assert (data[b * n:(b + 1) * n].cpu().numpy().view(np.uint32) == want).all()
+    finally:
+        ctx.destroy()
