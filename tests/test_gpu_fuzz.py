@@ -66,8 +66,8 @@ def test_random_shapes_against_oracle(ta):
 
 
 def test_random_folds_against_oracle(ta):
-    rng = np.random.default_rng(0xF01D)
-    for _ in range(60):
+    rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", "0"), 0) ^ 0xF01D)   # default: the fixed 60 of every run
+    for _ in range(int(os.environ.get("TOYNI_FUZZ_CASES", "60"))):
         log_m = int(rng.integers(1, 19))
         m = 1 << log_m
         shift = int(rng.integers(1, P))
@@ -93,8 +93,8 @@ def test_random_folds_against_oracle(ta):
 
 
 def test_random_low_degree_extensions_against_oracle(ta):
-    rng = np.random.default_rng(0x1DE)
-    for _ in range(80):
+    rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", "0"), 0) ^ 0x1DE)
+    for _ in range(int(os.environ.get("TOYNI_FUZZ_CASES", "80"))):
         log_n = int(rng.integers(1, 21))
         n = 1 << log_n
         log_blowup = int(rng.integers(0, log_n + 1))
