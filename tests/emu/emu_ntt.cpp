@@ -193,7 +193,7 @@ static void test_field() {
         // lazy product accepts any u32 on the left
         uint32_t any = a * 2654435761u;
         CHECK(bb_reduce_2p(mont_mul_lazy(any, to_mont(b))) == (uint32_t)orc_bb_mul(any % BB_P, b), "lazy any %u %u", any, b);
-        if (it < 2000 && a) CHECK(bb_inv_dev(a) == (uint32_t)orc_bb_inverse(a), "inv %u", a);
+        if (it < 2000 && a) CHECK(from_mont(mont_inv_chain(to_mont(a))) == (uint32_t)orc_bb_inverse(a), "inv %u", a);
     }
     CHECK(from_mont(BB_R1) == 1u, "R1");
     CHECK(narrow_u64((uint64_t)BB_P + 5) == 5u, "narrow");
@@ -268,33 +268,47 @@ static void test_fold(int log_N, int layer, uint32_t shift) {
     CHECK(bad == 0, "fold_quad log_N=%d layer=%d: %zu mismatches", log_N, layer, bad);
 }
 
-// fold_xs_batch (16 outputs behind one inversion, Montgomery form throughout) against the oracle's fri_fold on explicit points,
-// with zero points inside a batch (their own inverse is 0; their neighbours' must be untouched)
-static void test_fold_xs_batch() {
+// fold_xs_batch (B outputs behind one inversion; points plain, the shared inverse carries beta / 2) against the oracle's fri_fold on
+// explicit points, with zero points inside a batch (their own inverse is 0; their neighbours' must be untouched); and
+// batch_inverse_scaled itself against the oracle's inverse, incl. the extreme residues
+template <int B>
+static void fold_xs_batch_case(uint64_t seed) {
     const size_t m = 64, half = m / 2;
     std::vector<uint64_t> evals(m), xs(m), want(half);
-    orc_fill_splitmix(evals.data(), m, 4242);
-    orc_fill_splitmix(xs.data(), m, 4343);
+    orc_fill_splitmix(evals.data(), m, seed);
+    orc_fill_splitmix(xs.data(), m, seed + 101);
     for (size_t i = 0; i < m; ++i) if (xs[i] == 0) xs[i] = 1;
-    const uint64_t beta = 987654321;
+    xs[0] = 1; xs[1] = BB_P - 1; xs[2] = 2; evals[0] = 0; evals[half] = BB_P - 1;    // extreme operands
+    const uint64_t beta = seed % 3 == 0 ? 0 : (seed % 3 == 1 ? BB_P - 1 : 987654321);
     orc_fri_fold(want.data(), evals.data(), m, xs.data(), beta);
-    const uint32_t beta_half_R = to_mont_host(bb_mul_host((uint32_t)beta, BB_HALF));
+    const uint32_t beta_half = bb_mul_host((uint32_t)beta, BB_HALF);
     size_t bad = 0;
-    for (size_t g = 0; g < half / 16; ++g) {
-        uint32_t x[16], a[16], b[16], r[16];
-        for (int j = 0; j < 16; ++j) { x[j] = (uint32_t)xs[16 * g + j]; a[j] = (uint32_t)evals[16 * g + j]; b[j] = (uint32_t)evals[16 * g + j + half]; }
-        fold_xs_batch<16>(x, a, b, beta_half_R, r);
-        for (int j = 0; j < 16; ++j) bad += r[j] != (uint32_t)want[16 * g + j];
-        // zero points at positions 3 and 15: their outputs are the plain average, everyone else's are unchanged
-        x[3] = 0; x[15] = 0;
-        uint32_t rz[16];
-        fold_xs_batch<16>(x, a, b, beta_half_R, rz);
-        for (int j = 0; j < 16; ++j) {
+    for (size_t g = 0; g < half / B; ++g) {
+        uint32_t x[B], a[B], b[B], r[B];
+        for (int j = 0; j < B; ++j) { x[j] = (uint32_t)xs[B * g + j]; a[j] = (uint32_t)evals[B * g + j]; b[j] = (uint32_t)evals[B * g + j + half]; }
+        fold_xs_batch<B>(x, a, b, beta_half, r);
+        for (int j = 0; j < B; ++j) bad += r[j] != (uint32_t)want[B * g + j];
+        uint32_t inv[B];
+        batch_inverse_scaled<B>(x, 1u, inv);                                          // x^-1 R
+        for (int j = 0; j < B; ++j) bad += from_mont(inv[j]) != (uint32_t)orc_bb_inverse(x[j]);
+        // zero points at the first, an inner and the last position: their outputs are the plain average, everyone else's are unchanged
+        const int z0 = 0, z1 = B > 2 ? B / 2 : 0, z2 = B - 1;
+        x[z0] = 0; x[z1] = 0; x[z2] = 0;
+        uint32_t rz[B];
+        fold_xs_batch<B>(x, a, b, beta_half, rz);
+        for (int j = 0; j < B; ++j) {
             const uint32_t avg = bb_halve(bb_add(a[j], b[j]));
-            bad += (j == 3 || j == 15) ? rz[j] != avg : rz[j] != r[j];
+            bad += (j == z0 || j == z1 || j == z2) ? rz[j] != avg : rz[j] != r[j];
         }
     }
-    CHECK(bad == 0, "fold_xs_batch: %zu mismatches", bad);
+    CHECK(bad == 0, "fold_xs_batch<%d> seed %llu: %zu mismatches", B, (unsigned long long)seed, bad);
+}
+static void test_fold_xs_batch() {
+    for (uint64_t seed = 4242; seed < 4242 + 12; ++seed) {
+        fold_xs_batch_case<16>(seed);
+        fold_xs_batch_case<4>(seed);
+        fold_xs_batch_case<1>(seed);
+    }
 }
 
 static void test_fold_ext(size_t len) {

@@ -2,7 +2,8 @@
 fold tests (layers up to 2^21) never reach them.
 
   fri_fold_stream_kernel<true,1024,2>    structured points, m * 4 B >= TOYNI_FOLD_NT_MIN_BYTES (256 MiB)          -> m = 2^26, 2^27
-  fri_fold_xs16_kernel                   explicit points, half >= 2^21, whole 16-groups, 16-byte aligned pointers -> m = 2^22, 2^24
+  fri_fold_xs16_kernel<NT,256>           explicit points, half >= 2^21, whole quads, 16-byte aligned pointers      -> m = 2^22 (+ a ragged
+                                         last chunk), 2^24; the non-temporal twin from m * 4 B >= 256 MiB         -> m = 2^26
   fri_fold_ext_stream_kernel<true,...>   Ext values, m * 16 B >= 256 MiB                                          -> m = 2^25
 
 Every output of every layer is compared with the oracle's fri_fold / fri_fold_ext (src/math/fri.rs:27-48, :7-25) -- bit-exact.
@@ -73,15 +74,17 @@ def test_structured_fold_stream_kernels_vs_oracle(ta, log_m, layer):
 
 
 @gpu
-@pytest.mark.parametrize("log_m", [22, 24])
-def test_explicit_point_fold_xs16_vs_oracle(ta, log_m):
+@pytest.mark.parametrize("m", [1 << 22, (1 << 22) + 8 * 1000, 1 << 24, 1 << 26])
+def test_explicit_point_fold_xs16_vs_oracle(ta, m):
+    # (2^22 + 8000: half is a multiple of 4 but not of the 4096 pairs a workgroup covers per iteration -- a ragged last chunk)
     lib = ta._lib.lib
-    m = 1 << log_m
     half = m // 2
-    rng = np.random.default_rng(200 + log_m)
+    rng = np.random.default_rng(200 + m % 1000 + m.bit_length())
     e = rng.integers(0, P, size=m, dtype=np.uint64)
     xs = rng.integers(1, P, size=half, dtype=np.uint64)            # arbitrary nonzero points, not a coset
-    zeros = [5, 16 * 1000 + 15, half - 16, half - 1]              # zero points inside 16-groups: first, middle, last group
+    # zero points: a thread's 16 points are quad tid of each of the four 256-quad runs of its 1024-quad chunk, so 5 / 5 + 1024 /
+    # 5 + 3072 share an inversion with one another; first, middle and last chunk
+    zeros = [5, 5 + 1024, 5 + 3072, 4096 * 100 + 4095, half - 16, half - 1]
     xs[zeros] = 0
     beta = 987654321
     want = oracle.fri_fold(e, np.where(xs == 0, np.uint64(1), xs), beta)
@@ -96,7 +99,8 @@ def test_explicit_point_fold_xs16_vs_oracle(ta, log_m):
         assert lib.toyni_stream_synchronize(None, None) == 0      # the call ran on the null stream
         got = do.download(np.uint32, half)
         assert (got == want).all(), np.flatnonzero(got != want)[:8]
-        assert _launched(ta, "fri_fold_xs16_kernel"), "the launcher did not take the 16-per-inversion kernel"
+        twin = "fri_fold_xs16_kernelILb1ELi256EE" if m * 4 >= (256 << 20) else "fri_fold_xs16_kernelILb0ELi256EE"
+        assert _launched(ta, twin), "the launcher did not take the 16-per-inversion kernel this size is about"
         # the same layer behind pointers that are only 4-byte aligned: must fall back to the 4-per-inversion kernel and agree
         de.upload(e.astype(np.uint32), offset=pad); dx.upload(xs.astype(np.uint32), offset=pad)
         ta._lib.check(lib.toyni_fri_fold_xs_device(de.ptr + pad, dx.ptr + pad, do.ptr + pad, m, beta, None), "fold")

@@ -136,6 +136,22 @@ TOYNI_HD uint32_t mont_dot2(uint32_t a, uint32_t bR, uint32_t c, uint32_t dR) {
     t += (uint64_t)m * BB_P;
     return bb_reduce_2p((uint32_t)(t >> 32));
 }
+// aR^(p-2) in the Montgomery domain (a R -> a^-1 R; 0 -> 0), BabyBear::inverse (src/babybear.rs:111-114) by an addition chain:
+// p - 2 = 0b111_0_(27 ones) = 15 * 2^27 - 1 is built as 0b1110 followed by nine times "shift by three, append 0b111":
+// 30 squarings + 11 products = 41 Montgomery products where the square-and-multiply ladder spends 30 + 30.
+TOYNI_HD uint32_t mont_inv_chain(uint32_t aR) {
+    const uint32_t x3 = mont_mul(mont_mul(aR, aR), aR);   // exponent 0b11
+    const uint32_t x7 = mont_mul(mont_mul(x3, x3), aR);   // 0b111
+    uint32_t r = mont_mul(x7, x7);                         // 0b1110
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        r = mont_mul(r, r);
+        r = mont_mul(r, r);
+        r = mont_mul(r, r);
+        r = mont_mul(r, x7);
+    }
+    return r;
+}
 TOYNI_HD uint32_t to_mont(uint32_t a) { return mont_mul(a, BB_R2); }
 TOYNI_HD uint32_t from_mont(uint32_t aR) { return mont_mul(aR, 1u); }
 

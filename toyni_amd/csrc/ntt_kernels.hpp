@@ -1340,53 +1340,49 @@ TOYNI_HD Ext4 fold_ext_one(const Ext4& a, const Ext4& b, uint32_t scaleR, const 
 }
 
 // ---- FRI fold with explicit points (the reference's signature fri_fold(evals, xs, beta)) ----
-// x^-1 by Fermat like src/babybear.rs:111-114, shared over BATCH elements with Montgomery's trick.
+// x^-1 by Fermat like src/babybear.rs:111-114, shared over B elements with Montgomery's trick.
 TOYNI_HD uint32_t bb_mul_plain(uint32_t a, uint32_t b) { return mont_mul(a, to_mont(b)); }
-TOYNI_HD uint32_t bb_inv_dev(uint32_t a) {
-    // a^(p-2), p-2 = 0x77FFFFFF
-    const uint32_t aR = to_mont(a);
-    uint32_t r = BB_R1;  // Montgomery one
-    uint32_t base = aR;
-    uint32_t e = BB_P - 2u;
-    for (int i = 0; i < 31; ++i) {
-        if (e & 1u) r = mont_mul(r, base);
-        base = mont_mul(base, base);
-        e >>= 1;
+
+// cw[j] = f * x_j^-1 * R (the Montgomery form of f / x_j, canonical) for B PLAIN canonical points behind ONE inversion; a zero point
+// rides along as 1 and gets 0 = f * pow(0, p - 2), what BabyBear::inverse computes without its zero assert (src/babybear.rs:111-114).
+// Round 4: no conversion of the points and no separate product with f.  With M(a, b) = a b / R and the points left in plain form the
+// powers of R that pile up are the same for every j, and they cancel:
+//   pre_j = R prod_{i<j} x_i / R^j                (pre_0 = R is never multiplied: pre_1 = x_0)
+//   inv   = R^2 / pre_B                           (pre_B read as a Montgomery form: mont_inv_chain)
+//   I_{B-1} = M(inv, f),  I_{j-1} = M(I_j, x_j)   ->  M(I_j, pre_j) = R f / x_j,  and M(I_0, pre_0) = I_0
+// so a point costs 3 products (prefix, back-substitution, cw) + 41 / B of the chain, and the I chain stays in [0, 2p) (mont_mul_lazy:
+// the left operand may be any u32): 13 instructions per point + 205 / B, where round 3's form (points to Montgomery form, (beta/2) as a
+// fourth product, the 60-product ladder) spent 30 + 300 / B.
+template <int B>
+TOYNI_HD void batch_inverse_scaled(const uint32_t (&x)[B], uint32_t f, uint32_t (&cw)[B]) {
+    uint32_t xn[B], pre[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) xn[j] = x[j] > 1u ? x[j] : 1u;
+    pre[0] = BB_R1;
+    uint32_t acc = xn[0];
+#pragma unroll
+    for (int j = 1; j < B; ++j) {
+        pre[j] = acc;
+        acc = mont_mul(acc, xn[j]);
     }
-    return from_mont(r);
+    uint32_t inv = mont_mul_lazy(mont_inv_chain(acc), f);
+#pragma unroll
+    for (int j = B - 1; j >= 1; --j) {
+        cw[j] = mont_mul(inv, pre[j]);
+        inv = mont_mul_lazy(inv, xn[j]);
+    }
+    cw[0] = bb_reduce_2p(inv);
+#pragma unroll
+    for (int j = 0; j < B; ++j) cw[j] &= 0u - (x[j] < 1u ? x[j] : 1u);   // all ones unless x_j = 0
 }
 
-
-// B outputs of the explicit-point fold behind ONE Fermat inversion (round 3; the 4-per-inversion kernel above stays for ragged tails):
-// everything in Montgomery form -- x_j R once, prefix products, (prod x)^-1 R by mont_inv-style exponentiation, back-substitution --
-// so an output costs 6 Montgomery products plus 1/B of the 46 of the inversion (B = 16: ~9) where the round-2 kernel spent ~20
-// (its products went through plain form, two reductions each, and four outputs shared an inversion).  A zero point rides along as
-// 1 and gets inverse 0 = pow(0, p - 2), exactly as in fri_fold_xs_kernel.  r[j] = (a_j + b_j)/2 + (a_j - b_j) (beta/2) / x_j.
+// B outputs of the explicit-point fold behind one inversion: r[j] = (a_j + b_j)/2 + (a_j - b_j) (beta/2) / x_j; beta_half = beta / 2, PLAIN
 template <int B>
-TOYNI_HD void fold_xs_batch(const uint32_t (&x)[B], const uint32_t (&a)[B], const uint32_t (&b)[B], uint32_t beta_half_R, uint32_t (&r)[B]) {
-    uint32_t xR[B], pre[B];
-    bool zero[B];
-    uint32_t acc = BB_R1;                        // Montgomery one
+TOYNI_HD void fold_xs_batch(const uint32_t (&x)[B], const uint32_t (&a)[B], const uint32_t (&b)[B], uint32_t beta_half, uint32_t (&r)[B]) {
+    uint32_t cw[B];
+    batch_inverse_scaled<B>(x, beta_half, cw);
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-        zero[j] = x[j] == 0u;
-        xR[j] = zero[j] ? BB_R1 : to_mont(x[j]);
-        pre[j] = acc;                            // (x_0 .. x_{j-1}) R
-        acc = mont_mul(acc, xR[j]);
-    }
-    uint32_t inv = BB_R1, base = acc, e = BB_P - 2u;   // (prod x)^-1 R: a^(p-2), src/babybear.rs:111-114
-    for (int i = 0; i < 31; ++i) {
-        if (e & 1u) inv = mont_mul(inv, base);
-        base = mont_mul(base, base);
-        e >>= 1;
-    }
-#pragma unroll
-    for (int j = B - 1; j >= 0; --j) {
-        const uint32_t xinvR = zero[j] ? 0u : mont_mul(inv, pre[j]);   // x_j^-1 R
-        inv = mont_mul(inv, xR[j]);
-        const uint32_t cwR = mont_mul(xinvR, beta_half_R);             // (beta/2) x_j^-1 R
-        r[j] = bb_add(bb_halve(bb_add(a[j], b[j])), mont_mul(bb_sub_lazy(a[j], b[j]), cwR));
-    }
+    for (int j = 0; j < B; ++j) r[j] = bb_add(bb_halve(bb_add(a[j], b[j])), mont_mul(bb_sub_lazy(a[j], b[j]), cw[j]));
 }
 
 }  // namespace toyni

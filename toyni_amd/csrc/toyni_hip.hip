@@ -562,63 +562,78 @@ __global__ void __launch_bounds__(256) merkle_open_groups_kernel(const OpenGroup
     merkle_open_group(gs.g[blockIdx.y], (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
-// FRI fold, explicit points, 16 outputs per thread and per Fermat inversion (fold_xs_batch), 16-byte accesses; half a multiple of 16
-__global__ void __launch_bounds__(256) fri_fold_xs16_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
-                                                             uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half_R) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+// FRI fold, explicit points, 16 outputs per thread and per Fermat inversion (fold_xs_batch<16>), in the shape of fri_fold_stream_kernel:
+// a workgroup covers 4 * T consecutive quads per iteration and a thread takes quad tid of each of the four runs of T, so every
+// wave access is 1 KiB of consecutive memory (round 3 gave a thread 16 CONSECUTIVE elements: four 16-byte accesses at a 64-byte lane
+// stride, 4.4 TB/s at 2^27) -- Montgomery's trick does not care which 16 points share an inversion.  half a multiple of 4; quads
+// past the end ride along as the point 1 with zero values and are not stored.  NT: non-temporal accesses for layers far beyond the
+// Infinity Cache.
+template <bool NT, int T>
+__global__ void __launch_bounds__(T) fri_fold_xs16_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
+                                                           uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half) {
+    const uint64_t quads = half / 4;
     const uint4* ea = reinterpret_cast<const uint4*>(evals);
     const uint4* eb = reinterpret_cast<const uint4*>(evals + half);
     const uint4* xp = reinterpret_cast<const uint4*>(xs);
     uint4* o = reinterpret_cast<uint4*>(out);
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < half / 16; g += stride) {
+    const uint64_t chunk = 4u * T;
+    auto load = [](const uint4* p) {
+        if constexpr (NT) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+            return *p;
+        }
+    };
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < quads; c0 += (uint64_t)gridDim.x * chunk) {
         uint32_t x[16], a[16], b[16], r[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint4 xv = xp[4 * g + q], av = ea[4 * g + q], bv = eb[4 * g + q];
-            x[4 * q] = xv.x; x[4 * q + 1] = xv.y; x[4 * q + 2] = xv.z; x[4 * q + 3] = xv.w;
-            a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
-            b[4 * q] = bv.x; b[4 * q + 1] = bv.y; b[4 * q + 2] = bv.z; b[4 * q + 3] = bv.w;
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t q = c0 + (uint64_t)u * T + threadIdx.x;
+            uint4 xv = make_uint4(1u, 1u, 1u, 1u), av = make_uint4(0u, 0u, 0u, 0u), bv = av;
+            if (q < quads) { xv = load(xp + q); av = load(ea + q); bv = load(eb + q); }
+            x[4 * u] = xv.x; x[4 * u + 1] = xv.y; x[4 * u + 2] = xv.z; x[4 * u + 3] = xv.w;
+            a[4 * u] = av.x; a[4 * u + 1] = av.y; a[4 * u + 2] = av.z; a[4 * u + 3] = av.w;
+            b[4 * u] = bv.x; b[4 * u + 1] = bv.y; b[4 * u + 2] = bv.z; b[4 * u + 3] = bv.w;
         }
-        fold_xs_batch<16>(x, a, b, beta_half_R, r);
+        fold_xs_batch<16>(x, a, b, beta_half, r);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[4 * g + q] = make_uint4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t q = c0 + (uint64_t)u * T + threadIdx.x;
+            if (q < quads) {
+                if constexpr (NT) {
+                    u32x4 vr = {r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
+                    __builtin_nontemporal_store(vr, reinterpret_cast<u32x4*>(o + q));
+                } else {
+                    o[q] = make_uint4(r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]);
+                }
+            }
+        }
     }
 }
 
-// FRI fold, explicit points: 4 inversions share one Fermat exponentiation (Montgomery's trick)
+// FRI fold, explicit points, 4 outputs per thread and inversion (fold_xs_batch<4>): small layers and ragged tails.
+// A zero point is kept OUT of the shared product (it would zero the inverses of its three neighbours): batch_inverse_scaled lets it
+// ride along as 1 and forces its own inverse to 0 = pow(0, p-2), what BabyBear::inverse would compute without its zero assert
+// (src/babybear.rs:111-114); the host forms report TOYNI_E_ZERO_INVERSE instead.
 __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
-                                                           uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half_R) {
+                                                           uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t groups = (half + 3) / 4;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
-        uint32_t x[4], pre[4];
-        bool zero[4];
-        uint32_t acc = 1;
+        uint32_t x[4], a[4], b[4], r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t i = 4 * q + j;
-            x[j] = i < half ? xs[i] : 1u;
-            // a zero point is kept OUT of the shared product (it would zero the inverses of its three neighbours): it
-            // rides along as 1 and its own inverse is forced to 0 = pow(0, p-2), what BabyBear::inverse would compute
-            // without its zero assert (src/babybear.rs:111-114); the host forms report TOYNI_E_ZERO_INVERSE instead
-            zero[j] = x[j] == 0u;
-            if (zero[j]) x[j] = 1u;
-            pre[j] = acc;                       // product of x[0..j)
-            acc = bb_mul_plain(acc, x[j]);
+            const bool in = i < half;
+            x[j] = in ? xs[i] : 1u;
+            a[j] = in ? evals[i] : 0u;
+            b[j] = in ? evals[i + half] : 0u;
         }
-        uint32_t inv = bb_inv_dev(acc);         // acc != 0 by construction
+        fold_xs_batch<4>(x, a, b, beta_half, r);
 #pragma unroll
-        for (int j = 3; j >= 0; --j) {
-            const uint64_t i = 4 * q + j;
-            const uint32_t xinv = zero[j] ? 0u : bb_mul_plain(inv, pre[j]);
-            inv = bb_mul_plain(inv, x[j]);
-            if (i < half) {
-                const uint32_t a = evals[i], b = evals[i + half];
-                const uint32_t avg = bb_halve(bb_add(a, b));
-                const uint32_t cw = mont_mul(xinv, beta_half_R);  // beta/2 * x^-1 (plain)
-                out[i] = bb_add(avg, bb_mul_plain(bb_sub(a, b), cw));
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < half) out[4 * q + j] = r[j];
     }
 }
 
@@ -693,27 +708,16 @@ __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __res
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t groups = (half + 3) / 4;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
-        uint32_t x[4], pre[4];
-        bool zero[4];
-        uint32_t acc = 1;
+        uint32_t x[4], xinvR[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = 4 * q + j < half ? xs[4 * q + j] : 1u;
+        batch_inverse_scaled<4>(x, 1u, xinvR);   // x_j^-1 R; 0 for a zero point (see fri_fold_xs_kernel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t i = 4 * q + j;
-            x[j] = i < half ? xs[i] : 1u;
-            zero[j] = x[j] == 0u;               // see fri_fold_xs_kernel
-            if (zero[j]) x[j] = 1u;
-            pre[j] = acc;
-            acc = bb_mul_plain(acc, x[j]);
-        }
-        uint32_t inv = bb_inv_dev(acc);
-#pragma unroll
-        for (int j = 3; j >= 0; --j) {
-            const uint64_t i = 4 * q + j;
-            const uint32_t xinv = zero[j] ? 0u : bb_mul_plain(inv, pre[j]);
-            inv = bb_mul_plain(inv, x[j]);
             if (i < half) {
                 const uint4 a = evals[i], b = evals[i + half];
-                const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, to_mont(xinv), beta_half);
+                const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, xinvR[j], beta_half);
                 out[i] = make_uint4(r.c[0], r.c[1], r.c[2], r.c[3]);
             }
         }
@@ -2041,16 +2045,23 @@ int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint
     if (m == 0) return TOYNI_OK;
     if (beta >= BB_P) return TOYNI_E_RANGE;
     const uint64_t half = m / 2;
-    const uint32_t beta_half_R = to_mont_host(bb_mul_host(beta, BB_HALF));
-    // large layers of whole 16-output groups behind 16-byte aligned pointers: one inversion per 16 outputs.  Measured, alternating
+    const uint32_t beta_half = bb_mul_host(beta, BB_HALF);   // plain: batch_inverse_scaled folds it into the shared inverse
+    // large layers of whole quads behind 16-byte aligned pointers: one inversion per 16 outputs.  Measured, alternating
     // (profiles/r03_ab_fold_xs16.txt): 2^24 layer 46.6 -> 26.7 us (2.9 -> 5.0 TB/s of its 8 B per input element), 2^27 418 -> 238 us;
     // a 2^20 layer LOSES (6.8 -> 9.0 us: 32 768 threads with a four times longer serial chain each), hence the size gate.
+    // Round 4 (plain-form batch inversion, 41-product chain, coalesced quads): 2^24 23.5 us and less, see DESIGN 6.
     // TOYNI_FOLD_XS16=0: always the 4-per-inversion kernel (A/B).
     static const bool xs16 = [] { const char* e = std::getenv("TOYNI_FOLD_XS16"); return !(e && e[0] == '0'); }();
-    if (xs16 && half >= ((uint64_t)1 << 21) && (half & 15) == 0 && !(((uintptr_t)d_evals | (uintptr_t)d_xs | (uintptr_t)d_out) & 15))
-        hipLaunchKernelGGL(fri_fold_xs16_kernel, dim3(grid_for(half / 16)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
-    else
-        hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half_R);
+    if (xs16 && half >= ((uint64_t)1 << 21) && (half & 3) == 0 && !(((uintptr_t)d_evals | (uintptr_t)d_xs | (uintptr_t)d_out) & 15)) {
+        constexpr int T = 256;
+        const int grid = grid_for((half / 4 + 3) / 4, T);   // one thread per four quads
+        if ((uint64_t)m * 4 >= fold_nt_min_bytes())
+            hipLaunchKernelGGL((fri_fold_xs16_kernel<true, T>), dim3(grid), dim3(T), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half);
+        else
+            hipLaunchKernelGGL((fri_fold_xs16_kernel<false, T>), dim3(grid), dim3(T), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half);
+    } else {
+        hipLaunchKernelGGL(fri_fold_xs_kernel, dim3(grid_for((half + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_evals, d_xs, d_out, half, beta_half);
+    }
     return (int)hipGetLastError();
 }
 
