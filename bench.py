@@ -847,10 +847,10 @@ def main():
                 # inversion chain per 4 outputs, so the bound is VALU, not HBM: 8 B per input element (4 evals + 2 xs read, 2 written)
                 xs24 = torch.randint(1, P, (nn // 2,), dtype=torch.int32, device=dev)
                 t_xs = time_dev(lambda: toyni_amd.fri_fold_xs_device(p1, xs24.data_ptr(), o.data_ptr(), nn, 123456789, stream=stream), 20)
-                # round 3 (fold_xs_batch): 46 products of the shared inversion per SIXTEEN outputs plus 6 per output (to Montgomery form,
-                # prefix product, two for the back-substitution, the coefficient, the application): ~9 per output = 4.5 per input element,
+                # round 4 (batch_inverse_scaled): 41 products of the shared inversion per SIXTEEN outputs plus 4 per output (prefix product,
+                # back-substitution (3 instructions: lazy), the coefficient, the application): ~6.6 per output = 3.3 per input element,
                 # 5 VALU instructions each, plus the adds, against the 39.3 T lane-ops/s of that instruction class
-                xs_lane_ops, xs_ops_src = 4.5 * 5 + 8, "hand count (no committed counter profile found)"
+                xs_lane_ops, xs_ops_src = 3.3 * 5 + 8, "hand count (no committed counter profile found)"
                 import glob as _glob
                 for cf in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_counters_fold_xs.json")), reverse=True):
                     cj = json.load(open(cf))
@@ -862,11 +862,12 @@ def main():
                 xs_checked = verify_fold_samples(buf, o, nn, 123456789, xs_t=xs24)
                 extras["fri_fold_xs_m2^24"] = {
                     "us": t_xs * 1e6, "GBps": 8.0 * nn / t_xs / 1e9, "frac_of_hbm_peak": 8.0 * nn / t_xs / 1e9 / HBM_PEAK_GBPS,
-                    "elements_per_s": nn / t_xs, "bound": "valu", "verified": True, "verified_outputs": xs_checked,
+                    "elements_per_s": nn / t_xs, "bound": "hbm (access pattern) from 2^24 up; valu below", "verified": True, "verified_outputs": xs_checked,
                     "valu": {"lane_ops_per_input_element": xs_lane_ops, "source": xs_ops_src, "achieved_Tops": xs_lane_ops * nn / t_xs / 1e12, "peak_Tops": 39.3,
                              "frac": xs_lane_ops * nn / t_xs / 1e12 / 39.3},
                     "note": "toyni_fri_fold_xs_device on a 2^24 layer, explicit points resident in HBM; 8 B algorithmic per input element (4 evals + 2 xs "
-                            "read, 2 written); one Fermat inversion per 16 outputs (src/math/fri.rs:38-40 inverts per element); round 2's 4-per-inversion kernel moved 3.0 TB/s"}
+                            "read, 2 written); one Fermat inversion (41-product addition chain) per 16 outputs, points left in plain form, coalesced quads "
+                            "(src/math/fri.rs:38-40 inverts per element); round 3's form of the same kernel: 26.1 us = 5.1 TB/s, round 2's 4-per-inversion kernel 3.0 TB/s"}
                 del xs24
             # reference-shaped host-slice entry point (PCIe inclusive; never `value`)
             h = np.random.default_rng(1).integers(0, P, nn, dtype=np.uint64)

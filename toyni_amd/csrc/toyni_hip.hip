@@ -618,13 +618,14 @@ __global__ void __launch_bounds__(T) fri_fold_xs16_kernel(const uint32_t* __rest
 // (src/babybear.rs:111-114); the host forms report TOYNI_E_ZERO_INVERSE instead.
 __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __restrict__ evals, const uint32_t* __restrict__ xs,
                                                            uint32_t* __restrict__ out, uint64_t half, uint32_t beta_half) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t groups = (half + 3) / 4;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
+    // a workgroup covers 4 * 256 consecutive elements per iteration, a thread takes element tid of each of the four runs of 256
+    // (consecutive lanes touch consecutive words whatever the alignment; the four points behind one inversion need not be neighbours)
+    const uint64_t chunk = 4u * 256u;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < half; c0 += (uint64_t)gridDim.x * chunk) {
         uint32_t x[4], a[4], b[4], r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint64_t i = 4 * q + j;
+            const uint64_t i = c0 + (uint64_t)j * 256u + threadIdx.x;
             const bool in = i < half;
             x[j] = in ? xs[i] : 1u;
             a[j] = in ? evals[i] : 0u;
@@ -632,8 +633,10 @@ __global__ void __launch_bounds__(256) fri_fold_xs_kernel(const uint32_t* __rest
         }
         fold_xs_batch<4>(x, a, b, beta_half, r);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (4 * q + j < half) out[4 * q + j] = r[j];
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = c0 + (uint64_t)j * 256u + threadIdx.x;
+            if (i < half) out[i] = r[j];
+        }
     }
 }
 
@@ -705,16 +708,20 @@ __global__ void __launch_bounds__(T) fri_fold_ext_stream_kernel(const FoldExtArg
 // explicit base-field points (the reference's signature fri_fold_ext(evals, xs, beta))
 __global__ void __launch_bounds__(256) fri_fold_ext_xs_kernel(const uint4* __restrict__ evals, const uint32_t* __restrict__ xs,
                                                                uint4* __restrict__ out, uint64_t half, const ExtFactor beta_half) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t groups = (half + 3) / 4;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += stride) {
+    // a workgroup covers 4 * 256 consecutive elements per iteration and a thread takes element tid of each of the four runs of 256:
+    // every wave access is consecutive memory (the four points behind one inversion need not be neighbours)
+    const uint64_t chunk = 4u * 256u;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < half; c0 += (uint64_t)gridDim.x * chunk) {
         uint32_t x[4], xinvR[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = 4 * q + j < half ? xs[4 * q + j] : 1u;
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = c0 + (uint64_t)j * 256u + threadIdx.x;
+            x[j] = i < half ? xs[i] : 1u;
+        }
         batch_inverse_scaled<4>(x, 1u, xinvR);   // x_j^-1 R; 0 for a zero point (see fri_fold_xs_kernel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint64_t i = 4 * q + j;
+            const uint64_t i = c0 + (uint64_t)j * 256u + threadIdx.x;
             if (i < half) {
                 const uint4 a = evals[i], b = evals[i + half];
                 const Ext4 r = fold_ext_one(Ext4{{a.x, a.y, a.z, a.w}}, Ext4{{b.x, b.y, b.z, b.w}}, xinvR[j], beta_half);
@@ -2049,10 +2056,12 @@ int toyni_fri_fold_xs_device(const uint32_t* d_evals, const uint32_t* d_xs, uint
     // large layers of whole quads behind 16-byte aligned pointers: one inversion per 16 outputs.  Measured, alternating
     // (profiles/r03_ab_fold_xs16.txt): 2^24 layer 46.6 -> 26.7 us (2.9 -> 5.0 TB/s of its 8 B per input element), 2^27 418 -> 238 us;
     // a 2^20 layer LOSES (6.8 -> 9.0 us: 32 768 threads with a four times longer serial chain each), hence the size gate.
-    // Round 4 (plain-form batch inversion, 41-product chain, coalesced quads): 2^24 23.5 us and less, see DESIGN 6.
+    // Round 4 (plain-form batch inversion, 41-product chain, coalesced quads): 2^24 23.8 us, 2^27 243 -> 186 us; with the shorter chain
+    // the gate moved from 2^21 to 2^18 pairs (a 2^21-element layer 6.8 -> 4.4 us, 2^20 4.6 -> 4.0; below that every form sits on the
+    // ~4 us launch floor).
     // TOYNI_FOLD_XS16=0: always the 4-per-inversion kernel (A/B).
     static const bool xs16 = [] { const char* e = std::getenv("TOYNI_FOLD_XS16"); return !(e && e[0] == '0'); }();
-    if (xs16 && half >= ((uint64_t)1 << 21) && (half & 3) == 0 && !(((uintptr_t)d_evals | (uintptr_t)d_xs | (uintptr_t)d_out) & 15)) {
+    if (xs16 && half >= ((uint64_t)1 << 18) && (half & 3) == 0 && !(((uintptr_t)d_evals | (uintptr_t)d_xs | (uintptr_t)d_out) & 15)) {
         constexpr int T = 256;
         const int grid = grid_for((half / 4 + 3) / 4, T);   // one thread per four quads
         if ((uint64_t)m * 4 >= fold_nt_min_bytes())
