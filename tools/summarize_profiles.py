@@ -66,5 +66,16 @@ if os.path.exists(hf):
     json.dump(traffic, open(f"profiles/{tag}_traffic{suffix}.json", "w"), indent=1, sort_keys=True)
 bj = f"{src}/bench_under_rocprof.json"
 if os.path.exists(bj) and os.path.getsize(bj):
-    shutil.copy(bj, f"profiles/{tag}_bench_under_rocprof{suffix}.json")
+    # The bench line printed INSIDE the --stats run.  Its roofline.traffic was read from whatever profile was committed when the run
+    # started -- by construction the previous collection, not the one this very run produces -- so those fields (and their STALE note
+    # after a source change) say nothing about this library and are dropped; the traffic of THIS library is {tag}_traffic{suffix}.json.
+    line = json.loads(open(bj).read().strip().splitlines()[-1])
+    for obj in [line.get("roofline")] + [v.get("roofline") for v in (line.get("extras") or {}).values() if isinstance(v, dict)]:
+        if isinstance(obj, dict):
+            obj.pop("traffic", None)
+            obj.pop("traffic_source", None)
+    line["note_on_this_file"] = "bench.py under rocprofv3 --kernel-trace --stats (profiled runs clock lower); traffic fields removed, see the traffic file of the same tag"
+    if os.path.exists(hf):
+        line["csrc_sha256"] = open(hf).read().strip()
+    json.dump(line, open(f"profiles/{tag}_bench_under_rocprof{suffix}.json", "w"))
 print(json.dumps(traffic, indent=1)[:1500])
