@@ -74,9 +74,10 @@ def test_structured_fold_stream_kernels_vs_oracle(ta, log_m, layer):
 
 
 @gpu
-@pytest.mark.parametrize("m", [1 << 22, (1 << 22) + 8 * 1000, 1 << 24, 1 << 26])
+@pytest.mark.parametrize("m", [1 << 19, (1 << 19) + 8, 1 << 22, (1 << 22) + 8 * 1000, 1 << 24, 1 << 26])
 def test_explicit_point_fold_xs16_vs_oracle(ta, m):
-    # (2^22 + 8000: half is a multiple of 4 but not of the 4096 pairs a workgroup covers per iteration -- a ragged last chunk)
+    # (2^19: the smallest layer the launcher gives to this kernel; 2^19 + 8: one quad in the last chunk; 2^22 + 8000: half is a
+    # multiple of 4 but not of the 4096 pairs a workgroup covers per iteration -- a ragged last chunk)
     lib = ta._lib.lib
     half = m // 2
     rng = np.random.default_rng(200 + m % 1000 + m.bit_length())
@@ -84,7 +85,7 @@ def test_explicit_point_fold_xs16_vs_oracle(ta, m):
     xs = rng.integers(1, P, size=half, dtype=np.uint64)            # arbitrary nonzero points, not a coset
     # zero points: a thread's 16 points are quad tid of each of the four 256-quad runs of its 1024-quad chunk, so 5 / 5 + 1024 /
     # 5 + 3072 share an inversion with one another; first, middle and last chunk
-    zeros = [5, 5 + 1024, 5 + 3072, 4096 * 100 + 4095, half - 16, half - 1]
+    zeros = [5, 5 + 1024, 5 + 3072, 4096 * 50 + 4095, half - 16, half - 1]
     xs[zeros] = 0
     beta = 987654321
     want = oracle.fri_fold(e, np.where(xs == 0, np.uint64(1), xs), beta)
