@@ -67,7 +67,7 @@ def test_random_shapes_against_oracle(ta):
 
 def test_random_folds_against_oracle(ta):
     rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", "0"), 0) ^ 0xF01D)   # default: the fixed 60 of every run
-    for _ in range(int(os.environ.get("TOYNI_FUZZ_CASES", "60"))):
+    for case in range(int(os.environ.get("TOYNI_FUZZ_CASES", "60"))):
         log_m = int(rng.integers(1, 19))
         m = 1 << log_m
         shift = int(rng.integers(1, P))
@@ -90,6 +90,18 @@ def test_random_folds_against_oracle(ta):
             a.free()
             o.free()
         assert (got.astype(np.uint64) == want).all(), f"structured points m={m} ctx=2^{log_ctx} shift={shift}"
+        # the reference's signature takes ANY even length (src/math/fri.rs:28): ragged lengths around both explicit-point kernels' gates
+        # (half a multiple of 4 or not; below and above 2^18 pairs), a few zero points, arbitrary (non-coset) points
+        m2 = 2 * int(rng.integers(1, 1 << int(rng.integers(1, 21))))
+        e2 = rng.integers(0, P, size=m2, dtype=np.uint64)
+        x2 = rng.integers(1, P, size=m2 // 2, dtype=np.uint64)
+        want2 = oracle.fri_fold(e2, x2, beta)
+        assert (ta.fri_fold(e2, x2, beta) == want2).all(), f"explicit points, ragged m={m2}"
+        if case % 4 == 0:   # whole quads around the 16-per-inversion kernel's gate (2^18 pairs): a ragged last chunk, zero points among the points
+            m3 = 8 * int(rng.integers(1 << 15, 1 << 17))
+            e3 = rng.integers(0, P, size=m3, dtype=np.uint64)
+            x3 = rng.integers(1, P, size=m3 // 2, dtype=np.uint64)
+            assert (ta.fri_fold(e3, x3, beta) == oracle.fri_fold(e3, x3, beta)).all(), f"explicit points, whole quads m={m3}"
 
 
 def test_random_low_degree_extensions_against_oracle(ta):
