@@ -102,6 +102,11 @@ def test_random_folds_against_oracle(ta):
             e3 = rng.integers(0, P, size=m3, dtype=np.uint64)
             x3 = rng.integers(1, P, size=m3 // 2, dtype=np.uint64)
             assert (ta.fri_fold(e3, x3, beta) == oracle.fri_fold(e3, x3, beta)).all(), f"explicit points, whole quads m={m3}"
+            m4 = 2 * int(rng.integers(1, 6000))   # Ext values, explicit points (src/math/fri.rs:7-25): ragged over the kernel's 1024-element chunks
+            e4 = rng.integers(0, P, size=(m4, 4), dtype=np.uint64)
+            x4 = rng.integers(1, P, size=m4 // 2, dtype=np.uint64)
+            b4 = rng.integers(0, P, size=4, dtype=np.uint64)
+            assert (ta.fri_fold_ext(e4, x4, b4) == oracle.fri_fold_ext(e4, x4, b4)).all(), f"Ext explicit points, ragged m={m4}"
 
 
 def test_random_low_degree_extensions_against_oracle(ta):
