@@ -207,6 +207,25 @@ def run_matrix(ta, oracle, profile="default", log=print):
         finally:
             a.free(); o.free()
         ncases += 1
+    # the explicit-point fold above its 16-per-inversion gate (2^18 pairs), with one quad in the last chunk: the plain kernel by default,
+    # its non-temporal twin under the footprint knob (TOYNI_FOLD_NT_MIN_BYTES=0 in the `nt` profile)
+    m = (1 << 19) + 8
+    e = rng.integers(0, P, size=m, dtype=np.uint32)
+    xs = rng.integers(1, P, size=m // 2, dtype=np.uint32)
+    xs[[3, 3 + 1024, m // 2 - 1]] = 0
+    a, x, o = Dev(ta, e.nbytes), Dev(ta, xs.nbytes), Dev(ta, e.nbytes // 2)
+    try:
+        a.up(e); x.up(xs)
+        ta.fri_fold_xs_device(a.ptr, x.ptr, o.ptr, m, 424242)
+        ta._lib.check(ta._lib.lib.toyni_stream_synchronize(None, None), "sync")
+        x1 = np.where(xs == 0, 1, xs).astype(np.uint64)
+        want = oracle.fri_fold(e.astype(np.uint64), x1, 424242)
+        for i in np.flatnonzero(xs == 0):   # x^-1 := 0: only the average survives
+            want[i] = oracle.bb_mul(oracle.bb_add(int(e[i]), int(e[i + m // 2])), (P + 1) // 2)
+        assert (o.down(m // 2) == want).all(), "explicit-point fold"
+    finally:
+        a.free(); x.free(); o.free()
+    ncases += 1
     return ncases
 
 
