@@ -841,7 +841,17 @@ def main():
                     "verified_how": "outputs of the last timed launch, sampled (random + both ends + chunk seams), against the oracle's fri_fold on the gathered pairs; "
                                     "every output of the same kernel at 2^26 / 2^27: tests/test_gpu_fold_large.py",
                 }
-                del big, o2
+                # the same 2^27 layer through the reference's literal signature fri_fold(evals, xs, beta): explicit points resident in HBM
+                # (8 B algorithmic per input element: 4 evals + 2 points read, 2 written), the non-temporal 16-per-inversion kernel
+                xs27 = torch.randint(1, P, (1 << 26,), dtype=torch.int32, device=dev)
+                t_xs27 = time_dev(lambda: toyni_amd.fri_fold_xs_device(big.data_ptr(), xs27.data_ptr(), o2.data_ptr(), 1 << 27, 123456789, stream=stream), 20)
+                xs27_checked = verify_fold_samples(big, o2, 1 << 27, 123456789, xs_t=xs27)
+                extras["fri_fold_xs_m2^27"] = {
+                    "us": t_xs27 * 1e6, "GBps": 8.0 * (1 << 27) / t_xs27 / 1e9, "frac_of_hbm_peak": 8.0 * (1 << 27) / t_xs27 / 1e9 / HBM_PEAK_GBPS,
+                    "verified": True, "verified_outputs": xs27_checked,
+                    "note": "toyni_fri_fold_xs_device, 2^27 layer beyond the Infinity Cache: fri_fold_xs16_kernel<true, 256> (one 41-product Fermat chain per "
+                            "16 outputs, coalesced quads, non-temporal); round 3's kernel: 238-243 us"}
+                del big, o2, xs27
                 c27.destroy()
                 # the reference's OWN signature fri_fold(evals, xs, beta) device-resident (explicit points: VERDICT r2 bench gap): one Fermat
                 # inversion chain per 4 outputs, so the bound is VALU, not HBM: 8 B per input element (4 evals + 2 xs read, 2 written)
