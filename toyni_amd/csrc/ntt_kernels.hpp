@@ -806,13 +806,21 @@ struct Pass {
 // column kind needs only the twiddle column (column >> LQ); the row kind runs its four rows as the four coordinates q of one k_1
 // (row r of coordinate q at word 4 r + q: a wave's loads are 4-byte lanes at a 16-byte stride, the four waves of a row tile sharing
 // their lines -- these launches are cache-resident by construction -- and its stores the same 16-byte chunks as the base form's).
+//
+// Round 5: the STREAMING three-step shape (LE1 = 5: 32 elements per thread, tiles of 16 rows / columns, 1024 threads): a 2048-point
+// pass at the occupancy of the 32-wide 1024-point two-step shape (one workgroup per CU, ~150 KiB of LDS), run by the prefetching
+// kernel ntt_pass3s_kernel.  With it n = 2^21 is TWO sweeps (1024-point column pass + 2048-point closing pass) instead of three
+// 128-point ones.  Differences from the latency shapes: the step-1 stages take the radix-4 form (their table slices live in LDS),
+// the step-2 twiddles of a thread are the same for every group and every tile and stay in registers (Tw2), stores take the
+// buffer-resource form, and the row pitch is 2 mod 32 so that a step-3 group of 16 rows x 2 positions reads 32 different banks.
 template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false, int LQ_ = 0>
 struct Pass3 {
     static_assert(KIND == KIND_COL || KIND == KIND_ROW_T, "passes of multi-pass plans");
     static_assert(LQ_ == 0 || (LQ_ == 2 && LC == 2), "interleaved latency tiles: one element's four coordinates");
     static constexpr int LQ = LQ_;
-    static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 4, "step sizes");
+    static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 5, "step sizes");
     static constexpr int STEPS = 3;
+    static constexpr bool STREAM = LE1 == 5;
     static constexpr int LM = LE1 + LE2 + LE3, LLO = LE2 + LE3, LHM = LE1 + LE2;
     static constexpr int IN_STEP_LOG = LLO, OUT_STEP_LOG = LHM;
     static constexpr bool NT = NT_;
@@ -823,9 +831,14 @@ struct Pass3 {
     using Stg = Pass<KIND_ROW_N, 5, 5, 3>;              // the stage code is shared (static members, independent of the shape)
 
     static constexpr uint32_t PADC = C < 32 ? C : 0;
-    static constexpr uint32_t PITCH = (M + (M >> LE3)) | 1u;
+    static constexpr uint32_t PITCH = STREAM ? (M + (M >> LE3)) + ((2u + 32u - ((M + (M >> LE3)) & 31u)) & 31u) : ((M + (M >> LE3)) | 1u);
     static constexpr uint32_t LDS_WORDS = KIND == KIND_COL ? M * C + (M >> LE3) * PADC : C * PITCH;
-    static constexpr uint32_t TW_WORDS = M - E3;        // stages LE3 .. LM-1 of the packed stage table, kept in LDS
+    static constexpr uint32_t TW_WORDS = M - E3;        // stages LE3 .. LM-1 of the packed stage table, kept in LDS (latency shapes)
+    // streaming shapes: only step 1 reads its twiddles from LDS -- stages LLO .. LM-1 of the packed table and blocks LLO+1 .. LM-1 of
+    // its radix-4 companion
+    static constexpr bool STEP1_R4 = STREAM;
+    static constexpr uint32_t TW1S_WORDS = STREAM ? M - (1u << (LE2 + LE3)) : 0u;
+    static constexpr uint32_t TW3S_WORDS = STEP1_R4 ? M - (2u << (LE2 + LE3)) : 0u;
     static constexpr uint32_t MIN_WAVES = 4;
     // LDS word distance between two consecutive registers of a thread in step 1 / 2 / 3
     static constexpr uint32_t STRIDE1 = KIND == KIND_COL ? (C << LLO) + (PADC << LE2) : (1u << LLO) + (1u << LE2);
@@ -907,6 +920,9 @@ struct Pass3 {
     }
     // twiddle slice kept in LDS: words [E3 - 1, M - 1) of the packed stage table; `tw` below points at its first word
     static TOYNI_HD const uint32_t* tw_global(const PassArgs& a) { return a.stage_tw + (E3 - 1u); }
+    // streaming shapes: the step-1 slices (the stage table from stage LLO on; the companion from block LLO + 1 on)
+    static TOYNI_HD const uint32_t* tw1s_global(const PassArgs& a) { return a.stage_tw + ((1u << LLO) - 1u); }
+    static TOYNI_HD const uint32_t* tw3s_global(const PassArgs& a) { return a.stage_tw3 + ((2u << LLO) - 2u); }
 
     // ---- step 1: HBM -> registers (E elements: r = lo + (i << LLO)), coset input scaling, LE1 stages, park in LDS ----
     struct InSeedRaw { uint32_t lo, hi; };
@@ -935,8 +951,10 @@ struct Pass3 {
         for (uint32_t i = 0; i < E; ++i)
             x[i] = (live && i < NZ) ? ld32<NT_>(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step), off0) : 0u;
     }
+    // tw1: the packed stage table from stage LLO on; tw3: its radix-4 companion from block LLO + 1 on (streaming shapes only)
     template <int LZ = 0>
-    static TOYNI_HD void step1(const PassArgs& a, const InSeedRaw& seed, uint32_t tid, uint32_t (&x)[E], uint32_t* lds, const uint32_t* tw) {
+    static TOYNI_HD void step1(const PassArgs& a, const InSeedRaw& seed, uint32_t tid, uint32_t (&x)[E], uint32_t* lds, const uint32_t* tw1,
+                               const uint32_t* tw3 = nullptr) {
         constexpr uint32_t NZ = E >> (LZ < LE1 ? LZ : LE1);
         uint32_t c, lo;
         coords1(tid, c, lo);
@@ -948,8 +966,7 @@ struct Pass3 {
                 if (i + 1 < NZ) { tw0 = mont_mul_lazy(tw0, a.cs_g); TOYNI_PIN(tw0); }
             }
         }
-        const uint32_t* tw1 = tw + ((1u << LLO) - E3);   // the table from stage LLO on
-        if constexpr (LZ == 0) Stg::template stages<LE1, LLO>(x, tw1, lo, nullptr);
+        if constexpr (LZ == 0) Stg::template stages<LE1, LLO, STEP1_R4>(x, tw1, lo, nullptr, tw3);
         else Stg::template stages_lz<LE1, LLO, LZ, LE1 - 1>(x, tw1, lo, nullptr);
         const uint32_t base = lds_word(c, lo);
 #pragma unroll
@@ -967,6 +984,45 @@ struct Pass3 {
 #pragma unroll
             for (uint32_t j = 0; j < E2; ++j) x[j] = lds[base + j * STRIDE2];
             Stg::template stages<LE2, LE3>(x, tw, d, nullptr);
+#pragma unroll
+            for (uint32_t j = 0; j < E2; ++j) lds[base + j * STRIDE2] = x[j];
+        }
+    }
+
+    // streaming shapes: the twiddles of step 2 depend on the thread's d only -- the same for each of its groups and for every tile --
+    // so they are read once per workgroup lifetime and stay in registers: w[2^s - 1 + q] = w_{2^(s+LE3+1)}^(d + (q << LE3)), q < 2^s
+    struct Tw2 { uint32_t w[E2 - 1 ? E2 - 1 : 1]; };
+    static TOYNI_HD Tw2 load_tw2(const PassArgs& a, uint32_t tid) {
+        uint32_t c, aa, d;
+        coords2(tid, 0u, c, aa, d);
+        Tw2 t;
+#pragma unroll
+        for (int s = 0; s < LE2; ++s) {
+#pragma unroll
+            for (uint32_t q = 0; q < (1u << s); ++q) t.w[(1u << s) - 1u + q] = a.stage_tw[(1u << (s + LE3)) - 1u + d + (q << LE3)];
+        }
+        return t;
+    }
+    static TOYNI_HD void step2_regs(uint32_t tid, uint32_t* lds, const Tw2& tw) {
+#pragma unroll
+        for (uint32_t g = 0; g < G2; ++g) {
+            uint32_t c, aa, d;
+            coords2(tid, g, c, aa, d);
+            uint32_t x[E2];
+            const uint32_t base = lds_word(c, (aa << LLO) + d);
+#pragma unroll
+            for (uint32_t j = 0; j < E2; ++j) x[j] = lds[base + j * STRIDE2];
+#pragma unroll
+            for (int s = LE2 - 1; s >= 0; --s) {
+#pragma unroll
+                for (uint32_t i = 0; i < E2; ++i) {
+                    if (i & (1u << s)) continue;
+                    const uint32_t w = tw.w[(1u << s) - 1u + (i & ((1u << s) - 1u))];
+                    const uint32_t u = x[i], v = x[i + (1u << s)];
+                    x[i] = bb_add(u, v);
+                    x[i + (1u << s)] = mont_dot_sub(u, v, w, BB_P - w);
+                }
+            }
 #pragma unroll
             for (uint32_t j = 0; j < E2; ++j) lds[base + j * STRIDE2] = x[j];
         }
@@ -1035,6 +1091,9 @@ struct Pass3 {
             const uint32_t step = (out_offset(a, 0u, 1u << LHM) - out_offset(a, 0u, 0u)) << 2;
             char* obase = reinterpret_cast<char*>(t.out);
             uint32_t tw0 = seeds.a0[g];
+#if TOYNI_BUF
+            const BufRsrc ws = buf_rsrc(obase);
+#endif
 #pragma unroll
             for (uint32_t b = 0; b < E3; ++b) {
                 uint32_t v = x[cx_bitrev(b, LE3)];
@@ -1042,6 +1101,9 @@ struct Pass3 {
                     v = mont_mul(v, tw0);
                     if (b + 1 < E3) { tw0 = mont_mul_lazy(tw0, seeds.g); TOYNI_PIN(tw0); }
                 }
+#if TOYNI_BUF
+                if constexpr (STREAM) { stb32<NT_>(ws, off0, b * step, v); continue; }
+#endif
                 st32<NT_>(reinterpret_cast<uint32_t*>(obase + (uint64_t)b * step), off0, v);
             }
         }
@@ -1053,11 +1115,13 @@ struct Pass3 {
         const Tile t = tile_of(a, tile_id);
         uint32_t x[E];
         load_tile<LZ>(a, t, tid, x);
-        step1<LZ>(a, in_seed_issue(a, t, tid), tid, x, lds, tw_global(a));
+        if constexpr (STREAM) step1<LZ>(a, in_seed_issue(a, t, tid), tid, x, lds, tw1s_global(a), tw3s_global(a));
+        else step1<LZ>(a, in_seed_issue(a, t, tid), tid, x, lds, tw_global(a) + ((1u << LLO) - E3));
     }
     static TOYNI_HD void phase2(const PassArgs& a, uint32_t tile_id, uint32_t tid, uint32_t* lds) {
         (void)tile_id;
-        step2(tid, lds, tw_global(a));
+        if constexpr (STREAM) step2_regs(tid, lds, load_tw2(a, tid));
+        else step2(tid, lds, tw_global(a));
     }
     static TOYNI_HD void phase3(const PassArgs& a, uint32_t tile_id, uint32_t tid, const uint32_t* lds) {
         const Tile t = tile_of(a, tile_id);

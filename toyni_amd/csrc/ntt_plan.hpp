@@ -53,8 +53,21 @@ inline bool& split_small_first() {
     static bool v = [] { const char* env = std::getenv("TOYNI_SPLIT_SMALL_FIRST"); return env ? env[0] != '0' : true; }();
     return v;
 }
+// element `idx` of a comma-separated integer list in the environment (0 when absent)
+inline int plan_env_triple(const char* name, int idx) {
+    const char* env = std::getenv(name);
+    if (!env) return 0;
+    for (int i = 0; i < idx; ++i) {
+        while (*env && *env != ',') ++env;
+        if (!*env) return 0;
+        ++env;
+    }
+    return std::atoi(env);
+}
 inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES], bool latency = false) {
-    if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = (log_n + 1) / 2; logm[1] = log_n / 2; logm[2] = 0; return; }
+    // (the larger factor LAST, as in the two-pass plans below: at n = 2^21 the 2048-point pass is then the closing row pass, which has a
+    // streaming form -- contiguous rows in, 64-byte segments out -- besides the 4-wide latency form)
+    if (latency && has_latency_plan(log_n)) { npasses = 2; logm[0] = log_n / 2; logm[1] = (log_n + 1) / 2; logm[2] = 0; return; }
     if (log_n <= 10) { npasses = 1; logm[0] = log_n; logm[1] = logm[2] = 0; return; }
     const bool small_first = split_small_first();
     if (log_n <= 20) {
@@ -71,6 +84,13 @@ inline void split_passes(int log_n, int& npasses, int (&logm)[MAX_PASSES], bool 
     logm[0] = small_first ? c : a;
     logm[1] = b;
     logm[2] = small_first ? a : c;
+    // experiment switch TOYNI_SPLIT3="a,b,c": that split for the size a + b + c (column shapes exist for 6..10 stage bits, closing row
+    // shapes for 5..10); the A/B of profiles/r05_ab_split3.txt
+    static const int forced[3] = {plan_env_triple("TOYNI_SPLIT3", 0), plan_env_triple("TOYNI_SPLIT3", 1), plan_env_triple("TOYNI_SPLIT3", 2)};
+    if (forced[0] + forced[1] + forced[2] == log_n && forced[0] >= 6 && forced[0] <= 10 && forced[1] >= 6 && forced[1] <= 10 && forced[2] >= 5 &&
+        forced[2] <= 10) {
+        logm[0] = forced[0]; logm[1] = forced[1]; logm[2] = forced[2];
+    }
 }
 
 // packed stage table of size-M transform with root w_M: entry [2^t - 1 + x] = w_{2^(t+1)}^x, x < 2^t
@@ -239,6 +259,14 @@ inline int& wide_min_log_tiles32() {
     static int v = plan_env_int("TOYNI_WIDE_TILES", 12);  // 99: never the 64-wide shapes
     return v;
 }
+// launches of at least this many (log2) 32-wide tiles run a 2048-point pass in its streaming three-step shape (16-wide tiles, 32
+// elements per thread, ntt_pass3s_kernel) and n = 2^21 as the two sweeps of its "latency" plan; 99 = never (the three-pass plan)
+inline int& stream3_min_log_tiles32() {
+    static int v = plan_env_int("TOYNI_S3_TILES", 7);
+    return v;
+}
+// sizes whose two-pass plan has streaming shapes for both passes
+inline bool has_stream2_plan(int log_n) { return log_n == 21; }
 
 // LQ > 0: the interleaved (Ext, AoS) variants: the same table (a lone Ext vector counts as four transforms' worth of tiles), without
 // the 8-wide two-step shapes and the 2048-point latency plans.
@@ -247,6 +275,12 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
     // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
+    if constexpr (LQ == 0) {
+        if (log_m == 11 && kind == KIND_ROW_T && log_tiles32 >= stream3_min_log_tiles32()) {
+            if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false>{});
+            return true;
+        }
+    }
     if ((LQ == 0 && log_m == 11) || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m))) {
 #define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false, LQ>{}); return true; }
         if constexpr (LQ == 0) {   // 2048-point passes exist only in the base form's latency plans of n = 2^21 / 2^22

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const Pas
             TOYNI_SCHED_FENCE();
             first = false;
         }
-        P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw);
+        P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw + ((1u << P::LLO) - P::E3));
         TOYNI_SCHED_FENCE();
         TOYNI_LDS_BARRIER();
         TOYNI_SCHED_FENCE();
@@ -194,6 +194,61 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const Pas
         TOYNI_SCHED_FENCE();
         TOYNI_BARRIER();  // every wave has its step-3 LDS reads in registers before the tile is overwritten
         TOYNI_SCHED_FENCE();
+    }
+}
+
+// Streaming three-step passes (Pass3 with 32 elements per thread, round 5): the pipeline of ntt_pass_kernel around three steps.
+// The next tile's loads (and its seed lookups) are issued as soon as step 1 has parked the registers in LDS -- ahead of this
+// tile's E stores, so that the counted vmcnt wait at the top of the loop retires them while the stores drain -- and stay in flight
+// across both data barriers and steps 2 and 3.  The step-1 twiddle slices live in LDS, the step-2 twiddles in registers.
+template <class P, int LZ = 0>
+__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const PassArgs a, const uint32_t ntiles) {
+    static_assert(P::STREAM && P::G3 * P::E3 == P::E && P::E <= 63, "stores per tile per thread");
+    __shared__ uint32_t lds[P::LDS_WORDS + P::TW1S_WORDS + P::TW3S_WORDS];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v = blockIdx.x;
+    if (v >= ntiles) return;
+    uint32_t* lds_tw1 = lds + P::LDS_WORDS;
+    uint32_t* lds_tw3 = lds_tw1 + P::TW1S_WORDS;
+    uint32_t x[P::E];
+    typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
+    P::template load_tile<LZ>(a, t, tid, x);
+    typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
+    typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
+    const typename P::Uniform uni = P::load_uniform(a);
+    const typename P::Tw2 tw2 = P::load_tw2(a, tid);
+    for (uint32_t j = tid; j < P::TW1S_WORDS; j += P::T) lds_tw1[j] = P::tw1s_global(a)[j];
+    for (uint32_t j = tid; j < P::TW3S_WORDS; j += P::T) lds_tw3[j] = P::tw3s_global(a)[j];
+    TOYNI_WAIT_VMEM0();
+    __syncthreads();
+    while (true) {
+        TOYNI_WAIT_VMEM_ALLOW(P::E);   // this tile's loads were issued before the previous tile's E stores
+        P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw1, lds_tw3);
+        typename P::Seeds seeds = P::seeds_finish(a, raw);
+        TOYNI_SCHED_FENCE();
+        const uint32_t vn = v + gridDim.x;
+        const bool more = vn < ntiles;  // uniform
+        typename P::Tile tn = t;
+        if (more) {
+            tn = P::tile_of(a, P::tile_order(vn, ntiles));
+            P::template load_tile<LZ>(a, tn, tid, x);   // prefetch
+            raw = P::seeds_issue(a, tn, tid);
+            inraw = P::in_seed_issue(a, tn, tid);
+        }
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        P::step2_regs(tid, lds, tw2);
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        P::step3(a, t, tid, lds, seeds, uni);
+        if (!more) break;
+        TOYNI_SCHED_FENCE();
+        TOYNI_BARRIER();  // every wave has its step-3 LDS reads in registers before the tile is overwritten
+        TOYNI_SCHED_FENCE();
+        t = tn;
+        v = vn;
     }
 }
 
@@ -1169,7 +1224,8 @@ template <class P> constexpr int ext_prefetch() { return (kind_of<P>() == KIND_R
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
     if constexpr (P::STEPS == 3) {
-        hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        if constexpr (P::STREAM) hipLaunchKernelGGL((ntt_pass3s_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        else hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else if constexpr (LZ > 0) {  // LDE first pass: one kernel each
         hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else if constexpr (P::LQ > 0) {  // interleaved (Ext) shapes: one kernel each (no A/B twin)
@@ -1189,8 +1245,10 @@ unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
     static const int per_cu = [] {  // once per instantiation (thread-safe initialisation)
         int occ = 0;
         hipError_t qe;
-        if constexpr (P::STEPS == 3) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3_kernel<P, 0>, (int)P::T, 0);
-        else if constexpr (P::LQ > 0) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, ext_prefetch<P>()>, (int)P::T, 0);
+        if constexpr (P::STEPS == 3) {
+            if constexpr (P::STREAM) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3s_kernel<P, 0>, (int)P::T, 0);
+            else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3_kernel<P, 0>, (int)P::T, 0);
+        } else if constexpr (P::LQ > 0) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, ext_prefetch<P>()>, (int)P::T, 0);
         else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0);
         if (qe != hipSuccess || occ < 1) occ = 1;
         if (const char* env = std::getenv("TOYNI_WG_PER_CU")) { int v = std::atoi(env); if (v > 0) occ = v; }
@@ -1273,9 +1331,12 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     }
     // a lone transform (or a few) of n = 2^21 / 2^22: the two-pass latency plan, while its first pass has at most
     // 2^lat_max_log_tiles32() 32-wide tiles' worth of columns
-    const bool lat = lq == 0 && c->has_lat && pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
-                     (((uint64_t)batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32()) &&
-                     (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
+    // (round 5) n = 2^21 in launches of any size: the same two-pass plan -- its 2048-point closing pass has a streaming shape
+    // (dispatch_pass: Pass3<KIND_ROW_T, 5, 3, 3, 4>), two sweeps where the three-pass plan makes three
+    const bool lat_small = pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
+                           (((uint64_t)batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32());
+    const bool lat_stream = has_stream2_plan(c->plan.log_n) && stream3_min_log_tiles32() < 99;
+    const bool lat = lq == 0 && c->has_lat && (lat_small || lat_stream) && (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
     const NttPlan& plan = lat ? c->plan_lat : c->plan;
     size_t chunk = batch;
     if (c->chunk_elems && c->plan.npasses > 1) {
