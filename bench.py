@@ -441,7 +441,7 @@ class ToolsLib:
         self.lib = ctypes.CDLL(path)
         vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         sig = {"toyni_ntt_ctx_create": (ci, [ctypes.c_uint32, ci, ctypes.POINTER(vp)]), "toyni_ntt_ctx_destroy": (ci, [vp]),
-               "toyni_ntt_ctx_passes": (ci, [vp]), "toyni_ntt_device": (ci, [vp, vp, vp, sz, ci, vp]),
+               "toyni_ntt_ctx_passes": (ci, [vp]), "toyni_ntt_ctx_passes_for": (ci, [vp, sz]), "toyni_ntt_device": (ci, [vp, vp, vp, sz, ci, vp]),
                "toyni_ntt_ctx_timing": (ci, [vp, ci]), "toyni_ntt_ctx_timing_read": (ci, [vp, vp, vp])}
         for name, (res, args) in sig.items():
             f = getattr(self.lib, name)
@@ -457,7 +457,7 @@ class ToolsLib:
         rc = self.lib.toyni_ntt_device(h, ptr, ptr, batch, int(inverse), stream or None)
         assert rc == 0, f"tools transform: status {rc}"
 
-    def timed_region(self, h, fn):
+    def timed_region(self, h, fn, batch=None):
         """Runs fn() with launch timing on; returns {'forward': [ms per pass], 'inverse': [...], 'launches': {...}}."""
         assert self.lib.toyni_ntt_ctx_timing(h, 1) == 0
         fn()
@@ -465,7 +465,8 @@ class ToolsLib:
         cnt = (self.ct.c_uint32 * 6)()
         assert self.lib.toyni_ntt_ctx_timing_read(h, ms, cnt) == 0
         assert self.lib.toyni_ntt_ctx_timing(h, 0) == 0
-        npass = self.lib.toyni_ntt_ctx_passes(h)
+        # launches per transform of THIS batch (n = 2^21 runs its two-pass plan whatever the batch)
+        npass = self.lib.toyni_ntt_ctx_passes(h) if batch is None else self.lib.toyni_ntt_ctx_passes_for(h, batch)
         out = {"launches": {}}
         for d, name in enumerate(("forward", "inverse")):
             out[name] = [ms[3 * d + p] / cnt[3 * d + p] if cnt[3 * d + p] else None for p in range(npass)]
@@ -664,7 +665,7 @@ def main():
         tl.run(th, ptr, batch, True, stream)
         torch.cuda.synchronize()
         t0t = time.perf_counter()
-        region = tl.timed_region(th, tools_steps)  # reading the events synchronises
+        region = tl.timed_region(th, tools_steps, batch)  # reading the events synchronises
         tools_ms_per_step = (time.perf_counter() - t0t) / args.steps * 1e3
         tl.destroy(th)
     # forward + inverse leaves the batch unchanged: an end-to-end check of the timed region over EVERY transform (a skipped
@@ -706,7 +707,7 @@ def main():
                              f"(configs[3] repeated-prover batch), in place, inputs resident in HBM") if args.scaling == "weak" else
                             (f"forward+inverse NTT n=2^{args.log_n} (configs[1]) over {total_batch} transforms in the whole job, "
                              f"{total_batch // world}{'+1' if total_batch % world else ''} per GPU (configs[3] as written: SURVEY 8(d) C4), in place, inputs resident in HBM"),
-                "log_n": args.log_n, "batch_per_gpu": batch, "batch_total": total_batch, "passes_per_transform": ctx.passes,
+                "log_n": args.log_n, "batch_per_gpu": batch, "batch_total": total_batch, "passes_per_transform": ctx.passes_for(batch),
                 "parallelism": f"batch-sharded x{world}, no collective",
             },
             "gpu_event_ms_per_step": gpu_s / args.steps * 1e3,
@@ -715,7 +716,7 @@ def main():
 
     # ---- roofline of the dominant kernel: per-pass launch durations, HIP events on the launch stream ----
     if rank == 0:
-        npass = ctx.passes
+        npass = ctx.passes_for(batch)
         if region is not None:
             fwd_ms, inv_ms = region["forward"], region["inverse"]
             timing_src = (f"HIP events around each of the {sum(region['launches']['forward']) + sum(region['launches']['inverse'])} pass launches of "

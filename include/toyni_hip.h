@@ -85,6 +85,9 @@ uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* ctx);
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* ctx);
 int toyni_ntt_ctx_passes(const toyni_ntt_ctx* ctx);     /* HBM sweeps per transform of the context's plan (1..3); large batches
                                                           * of n = 2^11..2^13 run a single-sweep kernel instead of their 2 passes */
+/* HBM sweeps (= kernel launches) one toyni_ntt_device call on `batch` base-field transforms makes: the single-sweep kernel for large
+ * batches of n = 2^11..2^13, the two-pass plan of n = 2^21 (every batch) and of a lone n = 2^22 transform, else as above. */
+int toyni_ntt_ctx_passes_for(const toyni_ntt_ctx* ctx, size_t batch);
 /* Multi-pass transforms of a large batch are issued in chunks of about chunk_elems elements so that the
  * intermediate buffer stays cache-resident; 0 = whole batch at once (also env TOYNI_CHUNK_ELEMS). */
 int toyni_ntt_ctx_set_chunk(toyni_ntt_ctx* ctx, size_t chunk_elems);

@@ -3,7 +3,8 @@
 // UNVERIFIED BY rustc: the build image has no cargo/rustc.  Kept deliberately small.  What IS
 // verified (tests/test_rust_dropin.py): the exact hipcc and ar commands below, run in a scratch crate layout
 // (hip/ filled as INTEGRATION.md section 1 says), produce a libtoyni_hip.a that links into a host program with
-// exactly the libraries emitted at the bottom (-lamdhip64 -lstdc++).  It compiles toyni_hip.hip for gfx950 ONLY with hipcc, archives it, links amdhip64, and
+// the libraries emitted at the bottom (-lamdhip64 -lstdc++) plus -lm -lpthread, which rustc supplies on every link line as platform
+// libraries of std (the test, linking with bare gcc, passes them by hand).  It compiles toyni_hip.hip for gfx950 ONLY with hipcc, archives it, links amdhip64, and
 // emits `has_hip` -- which, unlike the reference's unused `has_cuda`, src/ntt.rs
 // really gates on, so `--features hip` on a box without ROCm still builds the CPU path.
 use std::{env, path::PathBuf, process::Command};

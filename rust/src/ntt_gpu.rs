@@ -34,7 +34,9 @@ mod gpu {
     }
 
     // &mut [BabyBear] is handed over as *mut u64 (same guarantee the reference asserts at src/ntt.rs:115-116)
-    const _: () = assert!(size_of::<BabyBear>() == size_of::<u64>() && align_of::<BabyBear>() == align_of::<u64>());
+    // (paths spelled out as the reference does: `size_of` / `align_of` are in the prelude only since Rust 1.80)
+    const _: () = assert!(std::mem::size_of::<BabyBear>() == std::mem::size_of::<u64>());
+    const _: () = assert!(std::mem::align_of::<BabyBear>() == std::mem::align_of::<u64>());
 
     /// Status of a C-ABI call as the `Err(String)` the reference builds from `cuda_get_error_string` (src/ntt.rs:163-166).
     /// `pub(crate)`: the optional bindings of INTEGRATION.md section 3 (fold, LDE) live in other modules of the crate.

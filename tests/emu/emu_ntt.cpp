@@ -49,6 +49,18 @@ static unsigned long long tiles_by_steps[4] = {0, 0, 0, 0};
 template <class P, int LZ = 0>
 static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
     ++tiles_by_steps[P::STEPS];
+    if constexpr (P::STEPS == 3) {
+        if constexpr (P::WAVE_LOCAL2) {
+            // the streaming row shapes have NO barrier between steps 1 and 2 (a wave's step 2 reads only what the same wave parked in
+            // step 1): stepped wave by wave, so a read of another wave's row would see the 0xDEADBEEF fill / the previous tile's data
+            for (uint32_t w = 0; w < P::T / 64; ++w) {
+                for (uint32_t tid = 64 * w; tid < 64 * (w + 1); ++tid) P::template phase1<LZ>(a, b, tid, lds);
+                for (uint32_t tid = 64 * w; tid < 64 * (w + 1); ++tid) P::phase2(a, b, tid, lds);
+            }
+            for (uint32_t tid = 0; tid < P::T; ++tid) P::phase3(a, b, tid, lds);
+            return;
+        }
+    }
     for (uint32_t tid = 0; tid < P::T; ++tid) P::template phase1<LZ>(a, b, tid, lds);
     if constexpr (P::STEPS >= 2) {
         for (uint32_t tid = 0; tid < P::T; ++tid) P::phase2(a, b, tid, lds);

@@ -103,6 +103,11 @@ def test_apply_script_patches_a_reference_checkout_mechanically(tmp_path):
     for t in ("fn test_cuda_available", "fn test_cuda_ntt_vs_cpu", "fn test_cuda_intt_roundtrip"):
         assert t in gpu_mod and t in ref_ntt, t
     assert "use self::{gpu_available as cuda_available" in gpu_mod
+    # nothing that depends on a recent prelude -- the layout guarantee is spelled as the reference spells it
+    # (src/ntt.rs:115-116): `size_of` / `align_of` are prelude items only since Rust 1.80
+    assert "std::mem::size_of::<BabyBear>() == std::mem::size_of::<u64>()" in gpu_mod
+    assert "std::mem::align_of::<BabyBear>() == std::mem::align_of::<u64>()" in gpu_mod
+    assert not re.search(r"(?<![:\w])(?:size_of|align_of)::<", new_ntt), "unqualified size_of / align_of"
     assert new_ntt.count("{") == new_ntt.count("}")
     # Cargo.toml: one [features] table, the new one; everything else as before
     cargo, ref_cargo = open(dst / "Cargo.toml").read(), open(os.path.join(REFERENCE, "Cargo.toml")).read()
@@ -146,7 +151,10 @@ def test_following_integration_md_produces_a_linkable_archive(tmp_path):
     exe = tmp_path / "host"
     # linked with plain cc-style driver flags (no hipcc at link time: rustc links with cc)
     res = subprocess.run(["gcc", "-o", str(exe), str(host_obj), str(oracle_obj), f"-L{out}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
-                          "-Wl,-Bstatic", "-ltoyni_hip", "-Wl,-Bdynamic", "-lamdhip64", "-lstdc++", "-lm", "-lpthread"],
+                          "-Wl,-Bstatic", "-ltoyni_hip", "-Wl,-Bdynamic", "-lamdhip64", "-lstdc++",
+                          # not emitted by build.rs on purpose: rustc adds the platform libraries of std (-lm -lpthread -ldl ...) to every
+                          # link line itself; a bare gcc link has to name them
+                          "-lm", "-lpthread"],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     # all ten symbols of the reference's extern block (src/ntt.rs:95-110; cudaGetDeviceCount comes from libcudart there) are in the archive

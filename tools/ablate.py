@@ -33,7 +33,7 @@ def child(lib_path, cases):
     lib.toyni_ntt_ctx_create.argtypes = [ctypes.c_uint32, ci, ctypes.POINTER(vp)]
     lib.toyni_malloc.argtypes = [ctypes.POINTER(vp), sz]
     lib.toyni_ntt_profile_passes.argtypes = [vp, vp, sz, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
-    lib.toyni_ntt_ctx_passes.argtypes = [vp]
+    lib.toyni_ntt_ctx_passes_for.argtypes = [vp, sz]
     lib.toyni_ntt_ctx_destroy.argtypes = [vp]
     lib.toyni_free.argtypes = [vp]
     for log_n, batch in cases:
@@ -44,7 +44,7 @@ def child(lib_path, cases):
         best = None
         for _ in range(3):
             assert lib.toyni_ntt_profile_passes(h, d, batch, 0, 10, ms, None) == 0
-            cur = [ms[p] for p in range(lib.toyni_ntt_ctx_passes(h))]
+            cur = [ms[p] for p in range(lib.toyni_ntt_ctx_passes_for(h, batch))]
             best = cur if best is None else [min(a, b) for a, b in zip(best, cur)]
         print(f"  2^{log_n} x {batch}: " + "  ".join(f"{t:.3f}" for t in best) + f"   sum {sum(best):.3f} ms", flush=True)
         lib.toyni_ntt_ctx_destroy(h)

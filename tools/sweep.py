@@ -64,7 +64,7 @@ def main():
         # elements run the single-sweep LDS kernel instead of the plan's two passes
         lds = (11 <= log_n <= int(os.environ.get("TOYNI_LDS_MAX_LOG", "13")) and batch * n >= int(os.environ.get("TOYNI_LDS_MIN_ELEMS", 1 << 25))
                and not lde and not os.environ.get("SWEEP_EXT"))
-        sweeps = 1 if lds else ctx.passes
+        sweeps = 1 if lds else (ctx.passes if (lde or os.environ.get("SWEEP_EXT")) else ctx.passes_for(batch))
         print(f"n=2^{log_n:<2d} batch={batch:<9d} sweeps={sweeps} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
               f"{8.0 * sweeps * batch * n / ms / 1e9:7.2f} TB/s moved  (windows +-{50 * spread:.1f} %)", flush=True)
         if toyni_amd._lib.HAS_TOOLS and os.environ.get("SWEEP_PASSES"):   # TOYNI_LIB_OVERRIDE=.../libtoyni_hip_tools.so

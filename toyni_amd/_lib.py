@@ -68,6 +68,7 @@ SIGNATURES = {
     "toyni_ntt_ctx_n": (c_u32, [c_void_p]),
     "toyni_ntt_ctx_device": (c_int, [c_void_p]),
     "toyni_ntt_ctx_passes": (c_int, [c_void_p]),
+    "toyni_ntt_ctx_passes_for": (c_int, [c_void_p, c_size]),
     "toyni_ntt_ctx_set_chunk": (c_int, [c_void_p, c_size]),
     "toyni_ntt_host": (c_int, [c_void_p, c_void_p, c_size, c_int]),
     "toyni_ntt_host_multi_gpu": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_size, c_int]),

@@ -899,7 +899,18 @@ struct Pass3 {
         if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
         else { lo = tid & ((1u << LLO) - 1u); c = tid >> LLO; }
     }
+    // Streaming row kind: step 1 parks row c = (wave index) -- coords1 puts one row on 2^LLO = 64 consecutive lanes -- and step 2 of a
+    // row touches that row only, so each wave runs step 2 on ITS OWN row: the step-1 -> step-2 exchange is wave-local (a wave's LDS
+    // operations execute in order) and the pass needs one data barrier per tile instead of two.
+    static constexpr bool WAVE_LOCAL2 = STREAM && KIND == KIND_ROW_T && LE2 + LE3 == 6;
     static TOYNI_HD void coords2(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& aa, uint32_t& d) {
+        if (WAVE_LOCAL2) {
+            const uint32_t l = tid & 63u;
+            c = tid >> 6;
+            d = l & (E3 - 1);
+            aa = (l >> LE3) + g * (64u >> LE3);
+            return;
+        }
         const uint32_t gamma = tid + g * T;
         if (KIND == KIND_COL) { c = gamma & (C - 1); d = (gamma >> LC) & (E3 - 1); aa = gamma >> (LC + LE3); }
         else { d = gamma & (E3 - 1); aa = (gamma >> LE3) & (E - 1); c = gamma >> (LE3 + LE1); }

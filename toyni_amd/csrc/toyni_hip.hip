@@ -202,16 +202,18 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const Pas
 // tile's E stores, so that the counted vmcnt wait at the top of the loop retires them while the stores drain -- and stay in flight
 // across both data barriers and steps 2 and 3.  The step-1 twiddle slices live in LDS, the step-2 twiddles in registers.
 template <class P, int LZ = 0>
-__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const PassArgs a, const uint32_t ntiles) {
+__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const PassArgs a, const uint32_t ntiles_flag) {
     static_assert(P::STREAM && P::G3 * P::E3 == P::E && P::E <= 63, "stores per tile per thread");
     __shared__ uint32_t lds[P::LDS_WORDS + P::TW1S_WORDS + P::TW3S_WORDS];
     const uint32_t tid = threadIdx.x;
-    uint32_t v = blockIdx.x;
+    const bool pairs = (ntiles_flag >> 31) != 0;   // EXPERIMENT: a workgroup runs tiles 2p, 2p + 1 back to back (they share 128-byte lines)
+    const uint32_t ntiles = ntiles_flag & 0x7FFFFFFFu;
+    uint32_t v = pairs ? 2u * blockIdx.x : blockIdx.x;
     if (v >= ntiles) return;
     uint32_t* lds_tw1 = lds + P::LDS_WORDS;
     uint32_t* lds_tw3 = lds_tw1 + P::TW1S_WORDS;
     uint32_t x[P::E];
-    typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
+    typename P::Tile t = P::tile_of(a, pairs ? v : P::tile_order(v, ntiles));
     P::template load_tile<LZ>(a, t, tid, x);
     typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
     typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
@@ -226,17 +228,18 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const Pa
         P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw1, lds_tw3);
         typename P::Seeds seeds = P::seeds_finish(a, raw);
         TOYNI_SCHED_FENCE();
-        const uint32_t vn = v + gridDim.x;
+        const uint32_t vn = pairs ? ((v & 1u) ? v + 2u * gridDim.x - 1u : v + 1u) : v + gridDim.x;
         const bool more = vn < ntiles;  // uniform
         typename P::Tile tn = t;
         if (more) {
-            tn = P::tile_of(a, P::tile_order(vn, ntiles));
+            tn = P::tile_of(a, pairs ? vn : P::tile_order(vn, ntiles));
             P::template load_tile<LZ>(a, tn, tid, x);   // prefetch
             raw = P::seeds_issue(a, tn, tid);
             inraw = P::in_seed_issue(a, tn, tid);
         }
         TOYNI_SCHED_FENCE();
-        TOYNI_LDS_BARRIER();
+        if constexpr (P::WAVE_LOCAL2) asm volatile("" ::: "memory");   // step 2 reads what this wave itself wrote: program order suffices
+        else TOYNI_LDS_BARRIER();
         TOYNI_SCHED_FENCE();
         P::step2_regs(tid, lds, tw2);
         TOYNI_SCHED_FENCE();
@@ -329,21 +332,51 @@ __global__ void __launch_bounds__(256) fourstep_twiddle_kernel(uint32_t* __restr
     }
 }
 
-// slab relayout (ntt_kernels.hpp): four consecutive output words per thread, 16-byte accesses on both sides (W >= 32)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the non-temporal builtins accept for 16-byte accesses
+
+// slab relayout (ntt_kernels.hpp): four consecutive output words per thread, 16-byte accesses on both sides (W >= 32).
+// Round 5: four quads in flight per thread and non-temporal accesses (the data is read once and written once, 512 MiB each way at
+// n = 2^27).  With one 16-byte load outstanding per thread a CU had 32 KiB in flight and the sweep moved 2.45 TB/s
+// (profiles/r04_bench_slab_2p27.json); the inverse form's twiddle is one table lookup pair per quad and a running product with
+// w_n^-k1 (the exponent k1 j' is linear in the column) instead of four independent lookups.
+__device__ __forceinline__ uint4 relayout_quad(const RelayoutArgs& a, uint4 v, uint32_t e0, uint32_t de) {
+    if (!a.inverse) return v;
+    const uint32_t lmask = (1u << a.lowbits) - 1u;
+    uint32_t tw = mont_mul(a.hi[e0 >> a.lowbits], a.lo[e0 & lmask]);
+    const uint32_t g = mont_mul(a.hi[de >> a.lowbits], a.lo[de & lmask]);   // w_n^-k1: the factor between neighbouring columns
+    uint4 r;
+    r.x = mont_mul(v.x, tw); tw = mont_mul_lazy(tw, g);
+    r.y = mont_mul(v.y, tw); tw = mont_mul_lazy(tw, g);
+    r.z = mont_mul(v.z, tw); tw = mont_mul_lazy(tw, g);
+    r.w = mont_mul(v.w, tw);
+    return r;
+}
 __global__ void __launch_bounds__(256) slab_relayout_kernel(const RelayoutArgs a, uint64_t quads) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
-        uint32_t e0, e3;
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; q + 3 * stride < quads; q += 4 * stride) {
+        u32x4 v[4];
+        uint32_t e0[4], e1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t src = relayout_src(a, 4 * (q + u * stride), e0[u]);
+            (void)relayout_src(a, 4 * (q + u * stride) + 1, e1[u]);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.in + src));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint4 r = relayout_quad(a, make_uint4(v[u].x, v[u].y, v[u].z, v[u].w), e0[u], e1[u] - e0[u]);
+            u32x4 o;
+            o.x = r.x; o.y = r.y; o.z = r.z; o.w = r.w;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(a.out + 4 * (q + u * stride)));
+        }
+    }
+    for (; q < quads; q += stride) {
+        uint32_t e0, e1;
         const uint64_t src = relayout_src(a, 4 * q, e0);
-        (void)relayout_src(a, 4 * q + 3, e3);
+        (void)relayout_src(a, 4 * q + 1, e1);
         const uint4 v = *reinterpret_cast<const uint4*>(a.in + src);
-        const uint32_t de = (e3 - e0) / 3u;  // the exponent is linear in w: k1 per step
-        uint4 r;
-        r.x = relayout_value(a, v.x, e0);
-        r.y = relayout_value(a, v.y, e0 + de);
-        r.z = relayout_value(a, v.z, e0 + 2u * de);
-        r.w = relayout_value(a, v.w, e3);
-        *reinterpret_cast<uint4*>(a.out + 4 * q) = r;
+        *reinterpret_cast<uint4*>(a.out + 4 * q) = relayout_quad(a, v, e0, e1 - e0);
     }
 }
 
@@ -357,7 +390,6 @@ __global__ void __launch_bounds__(256) domain_elements_kernel(uint32_t* __restri
     }
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the non-temporal builtins accept for 16-byte accesses
 
 // FRI fold, structured points; 4 outputs per thread through 16-byte accesses when the layer allows.
 // NT: non-temporal accesses for layers far larger than the Infinity Cache (read once, written once).
@@ -1224,7 +1256,11 @@ template <class P> constexpr int ext_prefetch() { return (kind_of<P>() == KIND_R
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
     if constexpr (P::STEPS == 3) {
-        if constexpr (P::STREAM) hipLaunchKernelGGL((ntt_pass3s_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
+        if constexpr (P::STREAM) {
+            static const bool pair_order = plan_env_int("TOYNI_S3_PAIRS", 0) != 0;
+            const bool pairs = pair_order && (ntiles & 1u) == 0 && grid * 2u <= ntiles;
+            hipLaunchKernelGGL((ntt_pass3s_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, pairs ? (ntiles | 0x80000000u) : ntiles);
+        }
         else hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else if constexpr (LZ > 0) {  // LDE first pass: one kernel each
         hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
@@ -1286,6 +1322,22 @@ struct PassTimer {
 #define TOYNI_PASS_TIMER(c, s, dir, pass) ((void)0)
 #endif
 
+// Which plan a launch of `batch` base-field transforms takes at n = 2^21 / 2^22 (the sizes with a second, two-pass plan):
+//   * a lone transform (or a few): the two-pass plan in its 4-wide latency shapes, while its first pass has at most
+//     2^lat_max_log_tiles32() 32-wide tiles' worth of columns;
+//   * (round 5) launches of any size where both passes have streaming shapes (has_stream2_plan): two sweeps where the
+//     three-pass plan makes three -- dispatch_pass picks the 16-wide streaming three-step shapes for the 2048-point passes.
+// Ext (interleaved) transforms keep the three-pass plan.
+bool use_two_pass_plan(const toyni_ntt_ctx* c, uint64_t batch, int lq, int lde_log) {
+    if (lq != 0 || !c->has_lat) return false;
+    if (lde_log != 0 && lde_log > c->plan_lat.pass[0].log_m) return false;
+    const bool lat_small = pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
+                           ((batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32());
+    // a low-degree extension reads 2^-lde_log of its first pass's input: the two sweeps win there even where the plain transform's do not
+    const bool lat_stream = stream3_min_log_tiles32() < 99 && (has_stream2_plan(c->plan.log_n) || (lde_log != 0 && has_latency_plan(c->plan.log_n)));
+    return lat_small || lat_stream;
+}
+
 int get_shift_table(toyni_ntt_ctx* c, uint32_t shift, ShiftTable** out);
 
 // Enqueue the passes of `batch` transforms on stream s (d_in == d_out allowed).  shift != 1: the coset scaling of
@@ -1329,14 +1381,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         if (!ok) return TOYNI_E_INVALID_SIZE;
         return (int)err;
     }
-    // a lone transform (or a few) of n = 2^21 / 2^22: the two-pass latency plan, while its first pass has at most
-    // 2^lat_max_log_tiles32() 32-wide tiles' worth of columns
-    // (round 5) n = 2^21 in launches of any size: the same two-pass plan -- its 2048-point closing pass has a streaming shape
-    // (dispatch_pass: Pass3<KIND_ROW_T, 5, 3, 3, 4>), two sweeps where the three-pass plan makes three
-    const bool lat_small = pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
-                           (((uint64_t)batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32());
-    const bool lat_stream = has_stream2_plan(c->plan.log_n) && stream3_min_log_tiles32() < 99;
-    const bool lat = lq == 0 && c->has_lat && (lat_small || lat_stream) && (lde_log == 0 || lde_log <= c->plan_lat.pass[0].log_m);
+    const bool lat = use_two_pass_plan(c, batch, lq, lde_log);
     const NttPlan& plan = lat ? c->plan_lat : c->plan;
     size_t chunk = batch;
     if (c->chunk_elems && c->plan.npasses > 1) {
@@ -1570,6 +1615,12 @@ int toyni_ntt_ctx_destroy(toyni_ntt_ctx* c) {
 uint32_t toyni_ntt_ctx_n(const toyni_ntt_ctx* c) { return c ? c->n : 0; }
 int toyni_ntt_ctx_device(const toyni_ntt_ctx* c) { return c ? c->device : -1; }
 int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 0 ? 0 : c->plan.npasses) : -1; }
+int toyni_ntt_ctx_passes_for(const toyni_ntt_ctx* c, size_t batch) {
+    if (!c) return -1;
+    if (c->plan.log_n == 0 || batch == 0) return 0;
+    if (lds_kernel_enabled(c->plan, batch)) return 1;
+    return use_two_pass_plan(c, batch, 0, 0) ? c->plan_lat.npasses : c->plan.npasses;
+}
 
 #ifdef TOYNI_TOOLS  // include/toyni_hip_tools.h
 int toyni_ntt_ctx_timing(toyni_ntt_ctx* c, int enable) {
@@ -2691,13 +2742,14 @@ int toyni_ntt_profile_passes(toyni_ntt_ctx* c, uint32_t* d_data, size_t batch, i
         int rc = grow(c, s, (void**)&sc.d_work, &sc.work_words, batch * (size_t)c->n, sizeof(uint32_t));
         if (rc) return rc;
     }
-    const uint32_t* tables = inverse ? c->d_inv : c->d_fwd;
+    const bool lat = use_two_pass_plan(c, batch, 0, 0);   // the plan toyni_ntt_device takes for this batch
+    const uint32_t* tables = lat ? (inverse ? c->d_inv_lat : c->d_fwd_lat) : (inverse ? c->d_inv : c->d_fwd);
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     int pass_index = 0;
     hipError_t err = hipSuccess;
-    bool ok = for_each_pass(c->plan, tables, inverse != 0, d_data, sc.d_work, d_data, batch,
+    bool ok = for_each_pass(lat ? c->plan_lat : c->plan, tables, inverse != 0, d_data, sc.d_work, d_data, batch,
                             [&](auto pass, auto, const PassArgs& a, uint64_t nblocks) {
                                 using P = decltype(pass);
                                 if (err != hipSuccess) return;

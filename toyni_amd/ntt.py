@@ -118,6 +118,10 @@ class NttContext:
     def passes(self) -> int:
         return lib.toyni_ntt_ctx_passes(self.handle)
 
+    def passes_for(self, batch: int) -> int:
+        """HBM sweeps one run_device call on `batch` transforms makes (the two-pass plan of 2^21, the single-sweep kernel of 2^11..2^13)."""
+        return lib.toyni_ntt_ctx_passes_for(self.handle, batch)
+
     def set_chunk(self, chunk_elems: int) -> None:
         check(lib.toyni_ntt_ctx_set_chunk(self.handle, chunk_elems), "set_chunk failed")
 
@@ -196,7 +200,7 @@ class NttContext:
         self._need_tools()
         out = (ctypes.c_float * 3)()
         check(lib.toyni_ntt_profile_passes(self.handle, d_data, batch, int(inverse), reps, out, stream or None), "profile failed")
-        return [out[i] for i in range(self.passes)]
+        return [out[i] for i in range(self.passes_for(batch) if self.passes == 3 else self.passes)]   # (the pass kernels, not the single-sweep one)
 
     def timing(self, enable: bool) -> None:
         """Bracket every pass launch of this context with HIP events on its launch stream (see read_timing)."""
