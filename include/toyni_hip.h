@@ -354,8 +354,9 @@ int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSy
  * hipStreamCaptureModeThreadLocal / Relaxed, or call toyni_ntt_ctx_trim (or a blocking entry point) before they start capturing. */
 int toyni_set_device(int device);
 /* Diagnostics: the symbols (one per line) of every kernel this process has launched through the library so far.  Returns the bytes
- * needed including the terminating 0; (NULL, 0) asks for the size.  With TOYNI_LAUNCH_LOG=<file> in the environment every newly seen
- * symbol is also appended to that file.  Used by the test suite to prove that every kernel of the shipped binary was run. */
+ * needed including the terminating 0; (NULL, 0) asks for the size.  An in-memory list only: the library writes no file and reads no
+ * environment variable for it.  Used by the test suite to prove that every kernel of the shipped binary was run (child processes of a
+ * test session dump this list at exit through the test harness). */
 size_t toyni_launched_kernels(char* buf, size_t cap);
 
 #ifdef __cplusplus

@@ -11,9 +11,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # Every kernel symbol the library launches during this session -- in this process and in every child process a test starts
-    # (measurement build, other dispatch knobs, compiled C++ hosts) -- is appended to this file by the library itself
-    # (TOYNI_LAUNCH_LOG, include/toyni_hip.h section 4); tests/test_zz_kernel_coverage.py reads it at the end of the session.
+    # Every kernel symbol the library launches during this session, in this process and in every child process a test starts (other
+    # dispatch knobs, ranks, compiled C++ hosts), ends up in this file: the library keeps an in-memory list (toyni_launched_kernels,
+    # include/toyni_hip.h section 4) and writes nothing itself; Python children dump the list at exit through tests/_hooks/sitecustomize.py
+    # (on PYTHONPATH below), the compiled hosts through tests/cpp/launch_dump.hpp.  tests/test_zz_kernel_coverage.py reads the file, plus
+    # this process's own list, at the end of the session.
+    hooks = os.path.join(ROOT, "tests", "_hooks")
+    if hooks not in os.environ.get("PYTHONPATH", "").split(os.pathsep):
+        os.environ["PYTHONPATH"] = hooks + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else "")
     if "TOYNI_LAUNCH_LOG" not in os.environ:
         import tempfile
         fd, path = tempfile.mkstemp(prefix="toyni_launch_log_", suffix=".txt")

@@ -3,6 +3,7 @@
 // src/verifier.rs, tests/harness/fib_verifier.py) and by bench.py (extras.fib_prove_*: wall time per proof, warm).
 //   fib_prove <trace_len> <seed> <reps> [proof.json] [--corrupt-row R] [--phases]
 // stdout: one JSON line {"trace_len":..,"lde_size":..,"folds":..,"final_layer_size":..,"ms":[..],"phases":{..}}
+#include "launch_dump.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -44,6 +45,7 @@ static bool write_proof(const char* path, const Proof& pr) {
 }
 
 int main(int argc, char** argv) {
+    struct DumpAtReturn { ~DumpAtReturn() { toyni_test_dump_launched_kernels(); } } dump_at_return;   // kernel-coverage guard of the test session
     if (argc < 4) { std::fprintf(stderr, "usage: %s <trace_len> <seed> <reps> [proof.json] [--corrupt-row R] [--phases]\n", argv[0]); return 2; }
     const size_t n = std::strtoull(argv[1], nullptr, 0);
     const uint64_t seed = std::strtoull(argv[2], nullptr, 0);

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../toyni_amd/csrc/host/toyni_ntt.hpp"
+#include "launch_dump.hpp"
 
 extern "C" {
 uint64_t orc_bb_new(uint64_t);
@@ -201,6 +202,7 @@ static void test_commit_phase_callback() {
 }
 
 int main() {
+    struct DumpAtReturn { ~DumpAtReturn() { toyni_test_dump_launched_kernels(); } } dump_at_return;   // kernel-coverage guard of the test session
     test_cuda_available();
     test_cuda_ntt_vs_cpu();
     test_cuda_intt_roundtrip();

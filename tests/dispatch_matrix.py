@@ -6,7 +6,8 @@ Used twice by tests/test_gpu_dispatch_matrix.py: in process with the default kno
 tests/dispatch_matrix.py <profile>`) under the dispatch knobs that reach the variants no default call selects at test sizes
 (TOYNI_NT_MIN_BYTES=0: the non-temporal twins, which a default call takes only from 512 MiB up; TOYNI_P3_TILES=-1: the two-step
 shapes on small launches; TOYNI_WIDE_TILES=0: 64-wide tiles; the single-sweep kernel's other workgroup shapes).  Every child
-appends the kernels it launched to $TOYNI_LAUNCH_LOG, which is what tests/test_zz_kernel_coverage.py judges.
+dumps the kernels it launched into $TOYNI_LAUNCH_LOG at exit (tests/_hooks/sitecustomize.py), which is what
+tests/test_zz_kernel_coverage.py judges.
 
 Checks per case, bit-exact: sampled transforms of the batch (first, last, one in the middle) against the oracle's
 domain_fft / ntt (src/math/domain.rs:107-123, src/ntt.rs:24-53), and the WHOLE batch through inverse(forward(x)) == x."""
@@ -63,8 +64,9 @@ def batches_for(log_n, cap_log_elems):
 
 # profile -> (sizes, batches beyond [1, 3]?, LDE sizes, Ext?, log2 cap on the elements of a case)
 PROFILES = {
-    "default": dict(sizes=range(1, 22), tiers=True, lde=(12, 14, 16, 18, 20, 21), ext=True, cap=26),
-    "nt": dict(sizes=range(8, 21), tiers=True, lde=(), ext=True, cap=24),
+    "default": dict(sizes=range(1, 22), tiers=True, lde=(12, 14, 16, 18, 20, 21, 22), ext=True, cap=26),
+    # (2^21 in the `nt` profile: the non-temporal twin of the streaming 2048-point closing pass, which a default call takes from 512 MiB up)
+    "nt": dict(sizes=range(8, 22), tiers=True, lde=(), ext=True, cap=24),
     "two_step": dict(sizes=range(11, 21), tiers=False, lde=(12, 14, 16, 18, 20), ext=True, cap=23),
     "two_step_nt": dict(sizes=range(11, 21), tiers=False, lde=(), ext=True, cap=23),
     "wide": dict(sizes=range(13, 20), tiers=False, lde=(), ext=True, cap=23),
@@ -178,7 +180,8 @@ def run_matrix(ta, oracle, profile="default", log=print):
             m1 = int(ta._lib.lib.toyni_ntt_ctx_first_pass_points(ctx_of(log_n).handle)).bit_length() - 1
             for z in range(1, min(5, m1) + 1):
                 # 1: latency shapes (two-step 8-wide under TOYNI_P3_TILES=-1); 4 / 16: the 16- and 32-wide tiles of a 1024-point first pass
-                for batch in ([1, 4, 16] if (full and log_n == 20) else [1, 16] if full and log_n < 20 else [1]):
+                # 2^21 / 2^22: a lone vector (latency shapes) and four (the two-pass plans' streaming shapes, 16-wide 2048-point passes)
+                for batch in ([1, 4, 16] if (full and log_n == 20) else [1, 16] if full and log_n < 20 else [1, 4] if full else [1]):
                     check_lde(log_n, batch, z, 7, False)
                     ncases += 1
                 if cfg["ext"] and log_n <= 20:

@@ -70,6 +70,7 @@ static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
     }
 }
 
+static uint64_t lde_batch = 2;      // "bN": vectors per low-degree-extension case ("lLOGxZ")
 static bool latency_plan = false;   // "Q1": n = 2^21 / 2^22 through their two-pass latency plan (2048-point three-step shapes)
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
@@ -662,12 +663,16 @@ int main(int argc, char** argv) {
             latency_plan = argv[i][1] == '1';
             continue;
         }
+        if (argv[i][0] == 'b') {                    // "bN": vectors per "l" case from here on
+            lde_batch = (uint64_t)std::atoll(argv[i] + 1);
+            continue;
+        }
         if (argv[i][0] == 'w') {                    // "wN": launches of >= 2^N 32-wide tiles take the 64-wide shapes of the 128/256-point passes
             wide_min_log_tiles32() = std::atoi(argv[i] + 1);
             continue;
         }
         if (argv[i][0] == 'l') {                    // "lLOGxZ": low-degree extension of 2^(LOG-Z) coefficients to 2^LOG points
-            test_lde(std::atoi(argv[i] + 1), 2, xb ? std::atoi(xb + 1) : 5, 7);
+            test_lde(std::atoi(argv[i] + 1), lde_batch, xb ? std::atoi(xb + 1) : 5, 7);
             std::printf("lde %s failures=%d\n", argv[i], failures);
             std::fflush(stdout);
             continue;

@@ -27,7 +27,9 @@ def test_dispatch_matrix_default_knobs(ta):
 @pytest.mark.parametrize("profile", sorted(dispatch_matrix.PROFILE_ENV))
 def test_dispatch_matrix_under_knob(ta, profile):
     # a child program (the knobs are read once per process); its launches are counted through TOYNI_LAUNCH_LOG (tests/conftest.py)
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]), **dispatch_matrix.PROFILE_ENV[profile])
+    # (tests/_hooks: the child dumps its launched-kernel list at exit for the coverage guard)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "_hooks")]),
+               **dispatch_matrix.PROFILE_ENV[profile])
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dispatch_matrix.py"), profile], capture_output=True, text=True,
                          timeout=540, env=env, cwd=ROOT)
     assert res.returncode == 0 and f"MATRIX OK profile={profile}" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]

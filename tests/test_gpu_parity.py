@@ -657,7 +657,7 @@ def _run_on_measurement_build(code, extra_env=None, timeout=300):
     import sys
     import __graft_entry__ as entry
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pp = os.pathsep.join([root, os.path.join(root, "tests")])
+    pp = os.pathsep.join([root, os.path.join(root, "tests"), os.path.join(root, "tests", "_hooks")])   # _hooks: the child reports its launches
     env = dict(os.environ, PYTHONPATH=pp, TOYNI_LIB_OVERRIDE=entry.build_tools(), **(extra_env or {}))
     return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
 

@@ -1,0 +1,99 @@
+"""Round 5: n = 2^21 as TWO sweeps -- 1024-point column pass + the streaming three-step 2048-point closing pass
+(Pass3<KIND_ROW_T, 5, 3, 3, 4>, ntt_pass3s_kernel) -- and the low-degree extensions that ride on the same two-pass plans
+(2^16 -> 2^21, what the prover and a downstream zkvm call per column: src/math/domain.rs:107-123, src/fibonacci.rs:101-103,125-128;
+2^17 -> 2^22 through the 16-wide 2048-point column shape with implied zero padding).
+
+Every transform of every batch is compared with the oracle (src/ntt.rs:24-66 restated), bit-exact; the launched kernel symbols are
+asserted, so a silent fall-back to the three-pass plan fails the test."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import P
+from test_gpu_parity import DevBuf, ta  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+STREAM_ROW = "ntt_pass3s_kernelIN5toyni5Pass3ILi1ELi5ELi3ELi3ELi4E"   # closing 2048-point pass, 16-row tiles
+STREAM_COL = "ntt_pass3s_kernelIN5toyni5Pass3ILi0ELi5ELi3ELi3ELi4E"   # 2048-point column pass (LDE first pass of n = 2^22)
+
+
+def _launched(ta, prefix):
+    return [k for k in ta._lib.launched_kernels() if prefix in k]
+
+
+@pytest.mark.parametrize("batch,shift,inplace,chunk_transforms", [
+    (4, 1, True, None),        # the smallest launch that takes the streaming shape (2^7 32-wide tiles' worth)
+    (5, 7, False, None),       # odd batch, coset (COSET_SHIFT, src/fibonacci.rs:16), out of place
+    (13, 1234567891, True, 6),  # chunked: launches of 6, 6 and 1 transforms -- the last one falls back to the latency shapes
+])
+def test_two_pass_2p21_every_transform_against_the_oracle(ta, batch, shift, inplace, chunk_transforms):
+    n = 1 << 21
+    rng = np.random.default_rng(0x5721 + batch)
+    x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+    x[:n] = (7 * np.arange(n, dtype=np.uint64) + 3) % P          # the reference's own input pattern (src/ntt.rs:272) in transform 0
+    ctx = ta.ntt.get_or_create_ctx(n)
+    assert ctx.passes == 3 and ctx.passes_for(batch) == 2 and ctx.passes_for(1) == 2
+    if chunk_transforms:
+        ctx.set_chunk(chunk_transforms * n)
+    a = DevBuf(ta, x.nbytes)
+    b = a if inplace else DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device(a.ptr, b.ptr, batch, False, shift=shift)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size)
+        for t in range(batch):
+            want = oracle.domain_fft(x[t * n:(t + 1) * n].astype(np.uint64), n, shift)
+            assert (y[t * n:(t + 1) * n] == want).all(), f"2^21 x{batch} shift {shift}: transform {t} differs from the oracle"
+        if not inplace:
+            assert (a.download(np.uint32, x.size) == x).all(), "out-of-place transform modified its input"
+        ctx.run_device(b.ptr, b.ptr, batch, True, shift=shift)
+        ctx.synchronize()
+        assert (b.download(np.uint32, x.size) == x).all(), "inverse(forward(x)) != x"
+    finally:
+        ctx.set_chunk(0)
+        a.free()
+        if b is not a:
+            b.free()
+    assert _launched(ta, STREAM_ROW), "the streaming 2048-point closing pass never ran"
+
+
+@pytest.mark.parametrize("log_n,z,batch", [
+    (21, 5, 5),     # the prover's LDE (2^16 -> 2^21, blow-up 32), ragged batch
+    (21, 5, 64),    # the batch bench.py times (extras.lde_64x_2^16_to_2^21); sampled vectors
+    (21, 2, 4),     # blow-up 4
+    (22, 5, 3),     # 2^17 -> 2^22: 16-wide 2048-point column pass with a zero fraction of 2^5
+    (22, 1, 2),     # blow-up 2
+    (22, 7, 4),     # blow-up 128: beyond five bits (the LZ = 5 variant with its row guard)
+])
+def test_lde_through_the_two_pass_plans(ta, log_n, z, batch):
+    n, n_in = 1 << log_n, (1 << log_n) >> z
+    rng = np.random.default_rng(0x1DE0 + log_n * 64 + z)
+    c = rng.integers(0, P, size=n_in * batch, dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, b = DevBuf(ta, c.nbytes), DevBuf(ta, 4 * n * batch)
+    try:
+        a.upload(c)
+        ctx.lde_device(a.ptr, b.ptr, batch, z, 7)
+        ctx.synchronize()
+        ts = range(batch) if batch <= 8 else sorted({0, 1, batch // 2, batch - 1})
+        for t in ts:
+            got = b.download(np.uint32, n, offset=4 * n * t)
+            want = oracle.domain_fft(c[t * n_in:(t + 1) * n_in].astype(np.uint64), n, 7)   # zero-pads, scales by 7^i, transforms
+            assert (got == want).all(), f"LDE 2^{log_n - z} -> 2^{log_n} x{batch}: vector {t} differs from the oracle"
+    finally:
+        a.free()
+        b.free()
+    assert _launched(ta, STREAM_ROW)
+    if log_n == 22:
+        assert any(f"EELi{min(z, 5)}EEv" in k for k in _launched(ta, STREAM_COL)), "the zero-fraction variant of the 2048-point column pass never ran"
+
+
+def test_plain_2p22_keeps_the_three_pass_plan_and_lone_transforms_the_latency_shapes(ta):
+    ctx22 = ta.ntt.get_or_create_ctx(1 << 22)
+    assert ctx22.passes == 3 and ctx22.passes_for(1) == 2 and ctx22.passes_for(2) == 2 and ctx22.passes_for(64) == 3
+    ctx21 = ta.ntt.get_or_create_ctx(1 << 21)
+    assert ctx21.passes_for(1) == 2 and ctx21.passes_for(1024) == 2
+    ctx13 = ta.ntt.get_or_create_ctx(1 << 13)
+    assert ctx13.passes == 2 and ctx13.passes_for(1) == 2 and ctx13.passes_for(1 << 12) == 1    # the single-sweep kernel from 2^25 elements

@@ -2,9 +2,10 @@
 test session that is just finishing -- so a kernel that the launcher picks only beyond some size, alignment or knob cannot ship
 without having been through a parity test.  (This file sorts last on purpose: pytest runs files in name order.)
 
-How: the library files the symbol of every kernel at the first launch of each launch site (toyni_launched_kernels; with
-TOYNI_LAUNCH_LOG in the environment also appended to that file, which tests/conftest.py sets for the session, so child processes
-count too).  The kernels the binary contains are the `Function Name:` remarks of the build that produced it
+How: the library files the symbol of every kernel at the first launch of each launch site in an in-memory list
+(toyni_launched_kernels; it writes no file itself).  Child processes of the session -- other dispatch knobs, ranks, the compiled
+C++ hosts -- dump their list at exit into $TOYNI_LAUNCH_LOG through the test harness (tests/_hooks/sitecustomize.py, which
+tests/conftest.py puts on PYTHONPATH; tests/cpp/launch_dump.hpp), so they count too.  The kernels the binary contains are the `Function Name:` remarks of the build that produced it
 (toyni_amd/lib/libtoyni_hip.resources.txt, written by __graft_entry__.build_hip).
 
 ALLOWED_UNLAUNCHED would list instantiations that exist without a path to them, each with its reason; it is empty."""

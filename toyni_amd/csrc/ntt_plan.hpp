@@ -265,15 +265,13 @@ inline int& stream3_min_log_tiles32() {
     static int v = plan_env_int("TOYNI_S3_TILES", 7);
     return v;
 }
-// sizes whose two-pass plan beats the three-pass one on streaming launches.  n = 2^21: 1024-point column pass + 2048-point closing
-// pass, 1.05 against 1.32 ms per 2^28 elements.  n = 2^22 (two 2048-point passes) does NOT qualify: its column pass works on 64-byte row
-// segments and the pair takes 1.32 ms against 1.24 for 7/7/8 (profiles/r05_ab_stream3.txt) -- but its low-degree extensions, whose
-// first pass reads 2^-blow-up of its input, do take the two sweeps (toyni_hip.hip: use_two_pass_plan)
-// (experiment switch TOYNI_S2_22=1: n = 2^22 as well)
-inline bool has_stream2_plan(int log_n) {
-    static const bool with22 = plan_env_int("TOYNI_S2_22", 0) != 0;
-    return log_n == 21 || (with22 && log_n == 22);
-}
+// Sizes whose two-pass plan beats the three-pass one on streaming launches.  n = 2^21: 1024-point column pass + 2048-point closing
+// pass, 1.05 against 1.32 ms per 2^28 elements.  n = 2^22 as two 2048-point passes was built and measured too and is NOT taken
+// (profiles/r05_ab_stream3.txt): 1.28-1.33 ms against 1.24-1.27 for 7/7/8 -- a 16-column tile means 64-byte row segments on both
+// sides of the column pass, and with the inter-pass twiddle that pass takes 0.71 ms where the closing pass takes 0.57.  What the
+// 16-wide column shape is kept for is the FIRST pass of a low-degree extension of n = 2^22 (it reads 2^-blow-up of its input:
+// 0.95 against 1.21 ms for 64 x 2^17 -> 2^22), so only its zero-fraction variants are instantiated (dispatch_pass_lz).
+inline bool has_stream2_plan(int log_n) { return log_n == 21; }
 
 // LQ > 0: the interleaved (Ext, AoS) variants: the same table (a lone Ext vector counts as four transforms' worth of tiles), without
 // the 8-wide two-step shapes and the 2048-point latency plans.
@@ -283,9 +281,8 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
     // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
     if constexpr (LQ == 0) {
-        if (log_m == 11 && log_tiles32 >= stream3_min_log_tiles32()) {
-            if (kind == KIND_ROW_T) { if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false>{}); }
-            else { if (nt) f(Pass3<KIND_COL, 5, 3, 3, 4, true>{}); else f(Pass3<KIND_COL, 5, 3, 3, 4, false>{}); }
+        if (log_m == 11 && kind == KIND_ROW_T && log_tiles32 >= stream3_min_log_tiles32()) {
+            if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false>{});
             return true;
         }
     }

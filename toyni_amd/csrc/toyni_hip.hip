@@ -28,32 +28,34 @@ using namespace toyni;
 // launch registry (toyni_launched_kernels, include/toyni_hip.h section 4)
 // ------------------------------------------------------------------------------------------------
 // Every launch site of this translation unit goes through the macro below: the FIRST launch of a site resolves the kernel's symbol
-// (hipKernelNameRefByPtr) and files it; every later one costs a relaxed load of a site-local flag.  tests/test_zz_kernel_coverage.py
-// compares the registry of a finished GPU test session with the kernel symbols of the shipped binary, so "every kernel the launcher
-// can pick has been through the parity tests" is a test, not a sentence.  TOYNI_LAUNCH_LOG=<file>: every newly filed
-// symbol is also appended to that file, so child processes of a test session (other dispatch knobs, the measurement build) count.
+// (hipKernelNameRefByPtr) and files it in an in-memory list; every later one costs a relaxed load of a site-local flag.
+// tests/test_zz_kernel_coverage.py compares the list of a finished GPU test session with the kernel symbols of the shipped binary, so
+// "every kernel the launcher can pick has been through the parity tests" is a test, not a sentence.  The library itself
+// writes NO file (rounds 3-4 appended to $TOYNI_LAUNCH_LOG from here: an environment-driven fopen in the product): child
+// processes of a test session dump toyni_launched_kernels() at exit through the test harness (tests/_hooks/sitecustomize.py for Python
+// children, tests/cpp/launch_dump.hpp for the compiled hosts).
 namespace launch_registry {
 inline std::mutex& mu() { static std::mutex m; return m; }
 inline std::vector<std::string>& names() { static std::vector<std::string> v; return v; }
-inline void note(const void* host_fn) {
+inline bool note(const void* host_fn) {
     const char* nm = hipKernelNameRefByPtr(host_fn, nullptr);
-    if (!nm) { (void)hipGetLastError(); return; }
+    if (!nm) { (void)hipGetLastError(); return false; }   // not filed: the site tries again at its next launch
     std::lock_guard<std::mutex> lk(mu());
     for (const auto& s : names())
-        if (s == nm) return;
+        if (s == nm) return true;
     names().push_back(nm);
-    if (const char* path = std::getenv("TOYNI_LAUNCH_LOG")) {
-        if (FILE* f = std::fopen(path, "a")) { std::fprintf(f, "%s\n", nm); std::fclose(f); }
-    }
+    return true;
 }
 }  // namespace launch_registry
 #undef hipLaunchKernelGGL
+// (the site flag is set only AFTER the symbol is in the list -- a concurrent toyni_launched_kernels() never sees a site marked whose
+// name is missing; two threads racing through a site's first launch both call note(), which files a name once)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                      \
     do {                                                                                                 \
         static std::atomic<bool> _toyni_site_seen{false};                                                \
-        if (!_toyni_site_seen.load(std::memory_order_relaxed)) {                                         \
-            _toyni_site_seen.store(true, std::memory_order_relaxed);                                     \
-            launch_registry::note(reinterpret_cast<const void*>(kernel));                                \
+        if (!_toyni_site_seen.load(std::memory_order_acquire)) {                                         \
+            if (launch_registry::note(reinterpret_cast<const void*>(kernel)))                            \
+                _toyni_site_seen.store(true, std::memory_order_release);                                 \
         }                                                                                                \
         kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                                     \
     } while (0)
@@ -202,18 +204,16 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3_kernel(const Pas
 // tile's E stores, so that the counted vmcnt wait at the top of the loop retires them while the stores drain -- and stay in flight
 // across both data barriers and steps 2 and 3.  The step-1 twiddle slices live in LDS, the step-2 twiddles in registers.
 template <class P, int LZ = 0>
-__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const PassArgs a, const uint32_t ntiles_flag) {
+__global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const PassArgs a, const uint32_t ntiles) {
     static_assert(P::STREAM && P::G3 * P::E3 == P::E && P::E <= 63, "stores per tile per thread");
     __shared__ uint32_t lds[P::LDS_WORDS + P::TW1S_WORDS + P::TW3S_WORDS];
     const uint32_t tid = threadIdx.x;
-    const bool pairs = (ntiles_flag >> 31) != 0;   // EXPERIMENT: a workgroup runs tiles 2p, 2p + 1 back to back (they share 128-byte lines)
-    const uint32_t ntiles = ntiles_flag & 0x7FFFFFFFu;
-    uint32_t v = pairs ? 2u * blockIdx.x : blockIdx.x;
+    uint32_t v = blockIdx.x;
     if (v >= ntiles) return;
     uint32_t* lds_tw1 = lds + P::LDS_WORDS;
     uint32_t* lds_tw3 = lds_tw1 + P::TW1S_WORDS;
     uint32_t x[P::E];
-    typename P::Tile t = P::tile_of(a, pairs ? v : P::tile_order(v, ntiles));
+    typename P::Tile t = P::tile_of(a, P::tile_order(v, ntiles));
     P::template load_tile<LZ>(a, t, tid, x);
     typename P::SeedsRaw raw = P::seeds_issue(a, t, tid);
     typename P::InSeedRaw inraw = P::in_seed_issue(a, t, tid);
@@ -228,11 +228,11 @@ __global__ void __launch_bounds__(P::T, P::MIN_WAVES) ntt_pass3s_kernel(const Pa
         P::template step1<LZ>(a, inraw, tid, x, lds, lds_tw1, lds_tw3);
         typename P::Seeds seeds = P::seeds_finish(a, raw);
         TOYNI_SCHED_FENCE();
-        const uint32_t vn = pairs ? ((v & 1u) ? v + 2u * gridDim.x - 1u : v + 1u) : v + gridDim.x;
+        const uint32_t vn = v + gridDim.x;
         const bool more = vn < ntiles;  // uniform
         typename P::Tile tn = t;
         if (more) {
-            tn = P::tile_of(a, pairs ? vn : P::tile_order(vn, ntiles));
+            tn = P::tile_of(a, P::tile_order(vn, ntiles));
             P::template load_tile<LZ>(a, tn, tid, x);   // prefetch
             raw = P::seeds_issue(a, tn, tid);
             inraw = P::in_seed_issue(a, tn, tid);
@@ -1256,11 +1256,7 @@ template <class P> constexpr int ext_prefetch() { return (kind_of<P>() == KIND_R
 template <class P, int LZ = 0>
 void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntiles) {
     if constexpr (P::STEPS == 3) {
-        if constexpr (P::STREAM) {
-            static const bool pair_order = plan_env_int("TOYNI_S3_PAIRS", 0) != 0;
-            const bool pairs = pair_order && (ntiles & 1u) == 0 && grid * 2u <= ntiles;
-            hipLaunchKernelGGL((ntt_pass3s_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, pairs ? (ntiles | 0x80000000u) : ntiles);
-        }
+        if constexpr (P::STREAM) hipLaunchKernelGGL((ntt_pass3s_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
         else hipLaunchKernelGGL((ntt_pass3_kernel<P, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
     } else if constexpr (LZ > 0) {  // LDE first pass: one kernel each
         hipLaunchKernelGGL((ntt_pass_kernel<P, 32, LZ>), dim3(grid), dim3(P::T), 0, s, a, ntiles);
