@@ -64,7 +64,7 @@ def batches_for(log_n, cap_log_elems):
 
 # profile -> (sizes, batches beyond [1, 3]?, LDE sizes, Ext?, log2 cap on the elements of a case)
 PROFILES = {
-    "default": dict(sizes=range(1, 22), tiers=True, lde=(12, 14, 16, 18, 20, 21, 22), ext=True, cap=26),
+    "default": dict(sizes=range(1, 23), tiers=True, lde=(12, 14, 16, 18, 20, 21, 22), ext=True, cap=26),
     # (2^21 in the `nt` profile: the non-temporal twin of the streaming 2048-point closing pass, which a default call takes from 512 MiB up)
     "nt": dict(sizes=range(8, 22), tiers=True, lde=(), ext=True, cap=24),
     "two_step": dict(sizes=range(11, 21), tiers=False, lde=(12, 14, 16, 18, 20), ext=True, cap=23),

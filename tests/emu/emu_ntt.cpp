@@ -46,6 +46,7 @@ static int failures = 0;
 
 // one tile of a pass, phase by phase: every thread runs phase k before any thread runs phase k + 1 (the pass' barriers)
 static unsigned long long tiles_by_steps[4] = {0, 0, 0, 0};
+static bool latency_plan = false;   // "Q1": n = 2^21 / 2^22 through their two-pass plans (2048-point three-step shapes)
 template <class P, int LZ = 0>
 static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
     ++tiles_by_steps[P::STEPS];
@@ -71,7 +72,6 @@ static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
 }
 
 static uint64_t lde_batch = 2;      // "bN": vectors per low-degree-extension case ("lLOGxZ")
-static bool latency_plan = false;   // "Q1": n = 2^21 / 2^22 through their two-pass latency plan (2048-point three-step shapes)
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 // LQ > 0: the interleaved (Ext, AoS) passes -- `batch` counts base-field transforms, 2^LQ of them interleaved word by word
@@ -154,7 +154,7 @@ static void test_coset(int log_n, uint64_t batch, uint32_t shift) {
 // compact coefficient vector ([n >> lde_log][4]) with the padding implied.
 static void test_ext(int log_n, uint64_t vectors, uint32_t shift, int lde_log = 0) {
     NttPlan plan;
-    CHECK(build_plan(log_n, plan), "plan %d", log_n);
+    CHECK(build_plan(log_n, plan, latency_plan && log_n == 21), "plan %d", log_n);   // "Q1": n = 2^21 through its two-pass plan (streaming closing pass)
     const size_t n = (size_t)1 << log_n, n_in = n >> lde_log;
     std::vector<uint64_t> ref(4 * n_in * vectors);
     orc_fill_splitmix(ref.data(), ref.size(), 0xE7700ull + (uint64_t)log_n * 131 + (uint64_t)lde_log);

@@ -29,7 +29,9 @@ def test_kernel_bodies_match_oracle_on_cpu():
                           # (round 5) the STREAMING 2048-point shapes of the same plans (16-wide tiles, 32 elements per thread, from 2^7 32-wide
                           # tiles' worth: four transforms of 2^21, two of 2^22): closing row pass (stepped wave by wave through steps 1 and 2 --
                           # it has no barrier there), the column pass as the first pass of an LDE in every zero fraction, coset forms
-                          "21x4", "21x5", "b4", "l21x5", "l21x2", "b2", "l22x5", "l22x1", "l22x2", "l22x3", "l22x4", "l22x8", "Q0"],
+                          "21x4", "21x5", "b4", "l21x5", "l21x2", "b2", "l22x5", "l22x1", "l22x2", "l22x3", "l22x4", "l22x8",
+                          # and the interleaved (Ext) form of the streaming closing pass: a lone vector and two, plain / coset / LDE by 32 and 4
+                          "e21", "e21x2", "Q0"],
                          capture_output=True, text=True, timeout=1800)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout

@@ -90,6 +90,44 @@ def test_lde_through_the_two_pass_plans(ta, log_n, z, batch):
         assert any(f"EELi{min(z, 5)}EEv" in k for k in _launched(ta, STREAM_COL)), "the zero-fraction variant of the 2048-point column pass never ran"
 
 
+@pytest.mark.parametrize("vectors,shift", [(1, 1), (3, 7)])
+def test_ext_vectors_of_2p21_through_the_two_pass_plan(ta, vectors, shift):
+    """fft_ext / ifft_ext (src/math/domain.rs:129-151) at n = 2^21: each coordinate of an AoS vector is the base transform of that
+    coordinate -- through the interleaved 1024-point column pass and the interleaved streaming 2048-point closing pass."""
+    n = 1 << 21
+    rng = np.random.default_rng(0xE57 + vectors)
+    x = rng.integers(0, P, size=4 * n * vectors, dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, b = DevBuf(ta, x.nbytes), DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device_ext_batch(a.ptr, b.ptr, vectors, False, shift=shift)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size).reshape(vectors, n, 4)
+        xx = x.reshape(vectors, n, 4)
+        for v in range(vectors):
+            for k in (range(4) if v == 0 else [v % 4]):
+                want = oracle.domain_fft(xx[v, :, k].astype(np.uint64), n, shift)
+                assert (y[v, :, k] == want).all(), f"ext 2^21 x{vectors} shift {shift}: vector {v} coordinate {k}"
+        ctx.run_device_ext_batch(b.ptr, b.ptr, vectors, True, shift=shift)
+        ctx.synchronize()
+        assert (b.download(np.uint32, x.size) == x).all(), "ifft_ext(fft_ext(x)) != x"
+        # LDE of Ext coefficients: 2^16 -> 2^21 (blow-up 32), the same buffers
+        c = x[:4 * (n >> 5) * vectors]
+        a.upload(c)
+        ctx.lde_ext_device(a.ptr, b.ptr, vectors, 5, 7)
+        ctx.synchronize()
+        y = b.download(np.uint32, 4 * n * vectors).reshape(vectors, n, 4)
+        cc = c.reshape(vectors, n >> 5, 4)
+        for v in range(vectors):
+            k = (v + 1) % 4
+            assert (y[v, :, k] == oracle.domain_fft(cc[v, :, k].astype(np.uint64), n, 7)).all(), f"ext LDE 2^16 -> 2^21: vector {v} coordinate {k}"
+    finally:
+        a.free()
+        b.free()
+    assert _launched(ta, "ntt_pass3s_kernelIN5toyni5Pass3ILi1ELi5ELi3ELi3ELi4ELb0ELi2E"), "the interleaved streaming closing pass never ran"
+
+
 def test_plain_2p22_keeps_the_three_pass_plan_and_lone_transforms_the_latency_shapes(ta):
     ctx22 = ta.ntt.get_or_create_ctx(1 << 22)
     assert ctx22.passes == 3 and ctx22.passes_for(1) == 2 and ctx22.passes_for(2) == 2 and ctx22.passes_for(64) == 3

@@ -816,7 +816,8 @@ struct Pass {
 template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false, int LQ_ = 0>
 struct Pass3 {
     static_assert(KIND == KIND_COL || KIND == KIND_ROW_T, "passes of multi-pass plans");
-    static_assert(LQ_ == 0 || (LQ_ == 2 && LC == 2), "interleaved latency tiles: one element's four coordinates");
+    static_assert(LQ_ == 0 || (LQ_ == 2 && (LC == 2 || (LC == 4 && KIND == KIND_ROW_T && LE1 == 5))),
+                  "interleaved tiles: one element's four coordinates (latency), or four rows x four coordinates (streaming row shape)");
     static constexpr int LQ = LQ_;
     static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 5, "step sizes");
     static constexpr int STEPS = 3;
@@ -844,8 +845,16 @@ struct Pass3 {
     static constexpr uint32_t STRIDE1 = KIND == KIND_COL ? (C << LLO) + (PADC << LE2) : (1u << LLO) + (1u << LE2);
     static constexpr uint32_t STRIDE2 = KIND == KIND_COL ? (C << LE3) + PADC : E3 + 1u;
     static constexpr uint32_t STRIDE3 = KIND == KIND_COL ? C : 1u;
+    // Interleaved streaming row shape (LQ = 2, 16 virtual rows c = (row << 2) | q): virtual row c is parked in LDS row 4 q + row.  With
+    // PITCH = 2 mod 32 a step-1 group of 32 lanes (4 coordinates x 8 consecutive positions of one row) then writes banks
+    // 8 q + 2 row + position -- 32 different ones -- and a step-3 group (the 16 virtual rows x 2 positions) reads all the even banks
+    // for one position and all the odd ones for the other (positions are 9 words apart).
+    static TOYNI_HD uint32_t lds_row(uint32_t c) {
+        if (LQ_ == 0 || KIND == KIND_COL || C != 16u) return c;
+        return ((c & 3u) << 2) + (c >> 2);
+    }
     static TOYNI_HD uint32_t lds_word(uint32_t c, uint32_t r) {
-        return KIND == KIND_COL ? r * C + c + (r >> LE3) * PADC : c * PITCH + r + (r >> LE3);
+        return KIND == KIND_COL ? r * C + c + (r >> LE3) * PADC : lds_row(c) * PITCH + r + (r >> LE3);
     }
 
     struct Tile {
@@ -897,12 +906,15 @@ struct Pass3 {
     // direction in step 2; in step 3 over the tile's columns / rows (contiguous in the output)
     static TOYNI_HD void coords1(uint32_t tid, uint32_t& c, uint32_t& lo) {
         if (KIND == KIND_COL) { c = tid & (C - 1); lo = tid >> LC; }
-        else { lo = tid & ((1u << LLO) - 1u); c = tid >> LLO; }
+        else if (LQ_ == 0 || C == 4u) { lo = tid & ((1u << LLO) - 1u); c = tid >> LLO; }
+        // interleaved rows of more than one element: the coordinates of one position are the fastest lanes (consecutive words in memory)
+        else { lo = (tid >> LQ_) & ((1u << LLO) - 1u); c = ((tid >> (LQ_ + LLO)) << LQ_) | (tid & ((1u << LQ_) - 1u)); }
     }
     // Streaming row kind: step 1 parks row c = (wave index) -- coords1 puts one row on 2^LLO = 64 consecutive lanes -- and step 2 of a
     // row touches that row only, so each wave runs step 2 on ITS OWN row: the step-1 -> step-2 exchange is wave-local (a wave's LDS
     // operations execute in order) and the pass needs one data barrier per tile instead of two.
-    static constexpr bool WAVE_LOCAL2 = STREAM && KIND == KIND_ROW_T && LE2 + LE3 == 6;
+    // (not the interleaved form: there a wave holds 16 positions of each of the four coordinates' rows)
+    static constexpr bool WAVE_LOCAL2 = STREAM && KIND == KIND_ROW_T && LE2 + LE3 == 6 && LQ_ == 0;
     static TOYNI_HD void coords2(uint32_t tid, uint32_t g, uint32_t& c, uint32_t& aa, uint32_t& d) {
         if (WAVE_LOCAL2) {
             const uint32_t l = tid & 63u;

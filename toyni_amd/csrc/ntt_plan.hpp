@@ -280,11 +280,10 @@ inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt =
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
     // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
-    if constexpr (LQ == 0) {
-        if (log_m == 11 && kind == KIND_ROW_T && log_tiles32 >= stream3_min_log_tiles32()) {
-            if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false>{});
-            return true;
-        }
+    // the streaming 2048-point closing pass (base and interleaved form; a lone Ext vector is already 2^7 32-wide tiles' worth at n = 2^21)
+    if (log_m == 11 && kind == KIND_ROW_T && log_tiles32 >= stream3_min_log_tiles32()) {
+        if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true, LQ>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false, LQ>{});
+        return true;
     }
     if ((LQ == 0 && log_m == 11) || (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m))) {
 #define TOYNI_PASS3_CASE(K, A, B, D) if (kind == K && log_m == (A) + (B) + (D)) { f(Pass3<K, A, B, D, 2, false, LQ>{}); return true; }

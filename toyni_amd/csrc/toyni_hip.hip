@@ -1272,13 +1272,15 @@ void launch_pass(unsigned grid, hipStream_t s, const PassArgs& a, uint32_t ntile
 
 // Grid of a persistent pass launch: every CU gets as many workgroups as fit (LDS / registers), capped by the tile
 // count; TOYNI_WG_PER_CU overrides the occupancy query (tuning knob).
-template <class P>
+// (LZ: the zero-fraction variant that will be launched -- only the streaming three-step shapes ask about that very instantiation, so
+// that no variant exists in the binary merely because its occupancy was queried)
+template <class P, int LZ = 0>
 unsigned persistent_grid(toyni_ntt_ctx* c, uint64_t ntiles) {
     static const int per_cu = [] {  // once per instantiation (thread-safe initialisation)
         int occ = 0;
         hipError_t qe;
         if constexpr (P::STEPS == 3) {
-            if constexpr (P::STREAM) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3s_kernel<P, 0>, (int)P::T, 0);
+            if constexpr (P::STREAM) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3s_kernel<P, LZ>, (int)P::T, 0);
             else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass3_kernel<P, 0>, (int)P::T, 0);
         } else if constexpr (P::LQ > 0) qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, ext_prefetch<P>()>, (int)P::T, 0);
         else qe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt_pass_kernel<P, 32>, (int)P::T, 0);
@@ -1323,10 +1325,14 @@ struct PassTimer {
 //     2^lat_max_log_tiles32() 32-wide tiles' worth of columns;
 //   * (round 5) launches of any size where both passes have streaming shapes (has_stream2_plan): two sweeps where the
 //     three-pass plan makes three -- dispatch_pass picks the 16-wide streaming three-step shapes for the 2048-point passes.
-// Ext (interleaved) transforms keep the three-pass plan.
+// Ext (interleaved) transforms: the two-pass plan at n = 2^21, the three-pass plan elsewhere.
 bool use_two_pass_plan(const toyni_ntt_ctx* c, uint64_t batch, int lq, int lde_log) {
-    if (lq != 0 || !c->has_lat) return false;
+    if (!c->has_lat) return false;
     if (lde_log != 0 && lde_log > c->plan_lat.pass[0].log_m) return false;
+    // Ext (interleaved) vectors: only where BOTH passes have interleaved streaming shapes (n = 2^21: the 1024-point column shapes and
+    // the 2048-point closing shape; there are no interleaved 2048-point latency or column shapes).  A lone vector is four transforms'
+    // worth of tiles -- 2^7 32-wide ones for the closing pass -- so every launch, chunked or not, reaches the streaming shape.
+    if (lq != 0) return has_stream2_plan(c->plan.log_n) && stream3_min_log_tiles32() <= 7;
     const bool lat_small = pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
                            ((batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32());
     // a low-degree extension reads 2^-lde_log of its first pass's input: the two sweeps win there even where the plain transform's do not
@@ -1406,7 +1412,7 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
             const int p = pass_index++;
             if (err != hipSuccess) return;
             TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, p);
-            launch_pass<P, LZ>(persistent_grid<P>(c, nblocks), s, a, (uint32_t)nblocks);
+            launch_pass<P, LZ>(persistent_grid<P, LZ>(c, nblocks), s, a, (uint32_t)nblocks);
             err = hipGetLastError();
         };
         bool ok = lq ? for_each_pass<2>(plan, tables, inverse, d_in + b0 * n_in, sc.d_work, d_out + b0 * n, nb, launch, cs, lde_log, nt)
