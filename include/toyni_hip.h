@@ -161,7 +161,8 @@ int toyni_fourstep_twiddle_device(toyni_ntt_ctx* ctx, uint32_t* d_data, size_t r
  * is an ordinary size-S1 transform (toyni_ntt_device on a size-S1 context):
  *   forward: slab pass (twiddle fused) -> all-to-all of contiguous row blocks -> relayout(0) -> size-S1 row transforms
  *   inverse: size-S1 inverse row transforms -> relayout(1) (twiddle fused) -> all-to-all -> slab pass(inverse)
- * Four HBM sweeps per direction at n = 2^27 instead of the eight of the transpose-based 4-step above.
+ * Four HBM sweeps per direction at n = 2^27 instead of the eight of the transpose-based 4-step above -- three with
+ * toyni_ntt_slab_rows_device, which folds the relayout into the row transforms' addressing.
  * Layouts: forward input / inverse output = slab [M1][cols_local], element (j1, c) = x[j1 S1 + col_base + c];
  *          forward output / inverse input = rows [rows_local][S1], element (r, k') = X[(row0 + r) + M1 k'].
  * cols_local and rows_local are powers of two, cols_local >= 32.  (src/ntt.rs:11-81 has no multi-device form: values
@@ -177,6 +178,16 @@ int toyni_ntt_slab_pass_device(toyni_ntt_ctx* ctx, uint32_t* d_slab, size_t cols
  * Out of place (d_in != d_out). */
 int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
                                    size_t parts, int inverse, void* stream);
+/* The relayout and the size-S1 row transforms as ONE step either side of the exchange (round 5), `row_ctx` = a context of size S1 on
+ * the same device:
+ *   inverse = 0: d_in = the received pieces [parts][rows_local][W]  ->  d_out = rows [rows_local][S1], transformed
+ *   inverse = 1: d_in = rows [rows_local][S1]  ->  d_out = pieces, inverse-transformed (1/S1) and times w_n^-((row0 + r) j')
+ * Where the pass shapes the launch takes can address the pieces layout, no relayout sweep exists: the first pass of the forward row
+ * transforms reads the pieces, the last pass of the inverse ones writes them -- three HBM sweeps per direction around the exchange
+ * instead of four; otherwise (a few rows, rows of at most 1024 points, a chunked context) the two steps above run one after the
+ * other.  Same results either way; *fused (may be NULL) reports which ran.  Out of place; the inverse form may overwrite d_in. */
+int toyni_ntt_slab_rows_device(toyni_ntt_ctx* ctx, toyni_ntt_ctx* row_ctx, uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
+                               size_t parts, int inverse, int* fused, void* stream);
 
 /* 2c. The same transform driven from ONE host process over G = ndev devices (G a power of two; Toyni is a single process,
  * src/ntt.rs:128-141): slab pass -> ONE exchange -> relayout -> row transforms on every device, contexts, streams and

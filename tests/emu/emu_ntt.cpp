@@ -456,6 +456,37 @@ static void emu_relayout(const NttPlan& plan, const uint32_t* in, uint32_t* out,
         out[o] = relayout_value(a, in[src], e);
     }
 }
+// toyni_ntt_slab_rows_device: the row transforms addressing the pieces layout directly (PassArgs::in_split_* / out_split_*, cs_mode 4).
+// Returns false when the dispatched shapes cannot (the library then runs relayout + transform; test_slab checks that form anyway).
+static unsigned long long slab_rows_fused = 0, slab_rows_fallback = 0;
+static bool emu_slab_rows(const NttPlan& big, const NttPlan& sub, bool inverse, const uint32_t* in, uint32_t* work, uint32_t* out, uint64_t rows,
+                          uint64_t row0, uint64_t parts) {
+    auto lg = [](uint64_t v) { int l = 0; while ((1ull << l) < v) ++l; return (uint32_t)l; };
+    SlabIo sio;
+    bool unsupported = false;
+    sio.log_parts = lg(parts);
+    sio.tw_lo = big.inv.data() + big.dom_lo_off;
+    sio.tw_hi = big.inv.data() + big.dom_hi_off;
+    sio.tw_lowbits = big.dom_lowbits;
+    sio.row0 = (uint32_t)row0;
+    sio.unsupported = &unsupported;
+    sio.dry = true;
+    const std::vector<uint32_t>& blob = inverse ? sub.inv : sub.fwd;
+    bool ok = sub.npasses >= 2 && rows >= 2 &&
+              for_each_pass<0>(sub, blob.data(), inverse, in, work, out, rows, [](auto, auto, const PassArgs&, uint64_t) {}, CosetTables(), 0, false, &sio);
+    if (!ok || unsupported) { ++slab_rows_fallback; return false; }
+    sio.dry = false;
+    ok = for_each_pass<0>(sub, blob.data(), inverse, in, work, out, rows, [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
+        using P = decltype(pass);
+        constexpr int LZ = decltype(lzc)::value;
+        std::vector<uint32_t> lds(P::LDS_WORDS, 0xDEADBEEFu);
+        for (uint64_t v = 0; v < nblocks; ++v) emu_tile<P, LZ>(a, P::tile_order((uint32_t)v, (uint32_t)nblocks), lds.data());
+    }, CosetTables(), 0, false, &sio);
+    CHECK(ok && !unsupported, "slab rows: dry run said yes, the run said no");
+    ++slab_rows_fused;
+    return true;
+}
+
 static void test_slab(int log_n, uint64_t G) {
     NttPlan plan, sub;
     CHECK(build_plan(log_n, plan), "plan %d", log_n);
@@ -482,6 +513,11 @@ static void test_slab(int log_n, uint64_t G) {
     for (uint64_t g = 0; g < G; ++g) {
         emu_relayout(plan, recv[g].data(), rows[g].data(), R, g * R, G, false);
         emu_transform(sub, false, rows[g].data(), work.data(), rows[g].data(), R);
+        {   // the fused form of the same two steps must produce the same rows (exactly sized buffers: an overrun is an ASan error)
+            std::vector<uint32_t> fused(R * s1, 0xFEFEFEFEu), fwork(R * s1);
+            if (emu_slab_rows(plan, sub, false, recv[g].data(), fwork.data(), fused.data(), R, g * R, G))
+                CHECK(fused == rows[g], "slab rows (fused, forward) log_n=%d G=%llu rank=%llu", log_n, (unsigned long long)G, (unsigned long long)g);
+        }
         uint64_t bad = 0;
         for (uint64_t r = 0; r < R; ++r)
             for (uint64_t k = 0; k < s1; ++k) bad += rows[g][r * s1 + k] != (uint32_t)want[(g * R + r) + m1 * k];
@@ -490,8 +526,11 @@ static void test_slab(int log_n, uint64_t G) {
     // inverse: back to the input slabs
     std::vector<std::vector<uint32_t>> send(G, std::vector<uint32_t>(R * s1));
     for (uint64_t g = 0; g < G; ++g) {
+        std::vector<uint32_t> fused(R * s1, 0xFEFEFEFEu), fwork(R * s1);
+        const bool did = emu_slab_rows(plan, sub, true, rows[g].data(), fwork.data(), fused.data(), R, g * R, G);   // rows[g] is only read
         emu_transform(sub, true, rows[g].data(), work.data(), rows[g].data(), R);
         emu_relayout(plan, rows[g].data(), send[g].data(), R, g * R, G, true);
+        if (did) CHECK(fused == send[g], "slab rows (fused, inverse) log_n=%d G=%llu rank=%llu", log_n, (unsigned long long)G, (unsigned long long)g);
     }
     for (uint64_t g = 0; g < G; ++g)
         for (uint64_t h = 0; h < G; ++h) std::memcpy(&slab[h][g * R * W], &send[g][h * R * W], R * W * sizeof(uint32_t));
@@ -726,6 +765,7 @@ int main(int argc, char** argv) {
     test_fold_ext(2);
     test_fold_ext(64);
     test_fold_ext(1024);
+    std::printf("slab rows: fused %llu, two-step form %llu\n", slab_rows_fused, slab_rows_fallback);
     std::printf("tiles stepped: one-step %llu, two-step %llu, three-step %llu\n", tiles_by_steps[1], tiles_by_steps[2], tiles_by_steps[3]);
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
     return failures ? 1 : 0;

@@ -25,7 +25,7 @@ def test_kernel_bodies_match_oracle_on_cpu():
                           # wN: launches of >= 2^N 32-wide tiles take the 64-wide shapes of the 128/256/512-point passes; w0 = always
                           "w0", "13", "14x3", "15", "16", "17x2", "18", "19", "21", "22", "s21x4", "s18x2", "e14x3", "e16x2", "e18",
                           # Q1: n = 2^21 / 2^22 through their two-pass latency plans (2048-point three-step shapes), plain / coset / LDE
-                          "w10", "p6", "Q1", "21", "22", "l21x5", "l21x3", "l22x5", "l21x11",
+                          "w10", "p6", "Q1", "21", "22", "l21x5", "l21x3", "l22x5", "l21x10", "l22x11",
                           # (round 5) the STREAMING 2048-point shapes of the same plans (16-wide tiles, 32 elements per thread, from 2^7 32-wide
                           # tiles' worth: four transforms of 2^21, two of 2^22): closing row pass (stepped wave by wave through steps 1 and 2 --
                           # it has no barrier there), the column pass as the first pass of an LDE in every zero fraction, coset forms

@@ -484,3 +484,49 @@ def test_stream_plumbing_for_hosts_without_a_hip_binding(ta):
     for p in (d, e):
         assert lib.toyni_free(p) == 0
     assert lib.toyni_stream_destroy(sa) == 0 and lib.toyni_stream_destroy(sb) == 0 and lib.toyni_stream_destroy(None) == 0
+
+
+@pytest.mark.parametrize("log_n,parts,rows,expect_fused", [
+    (22, 2, 128, (True, True)),    # 128-point first pass, rows of 2^15 = 128 x 256: two-step shapes on both sides
+    (22, 2, 64, (True, False)),    # half as many rows: the closing 256-point pass of the inverse takes its three-step latency shape -> two-step form
+    (26, 8, 32, (True, True)),     # configs[4]'s shapes one size down: rows of 2^18 = 512 x 512 (the (5,4) column and closing shapes)
+    (27, 8, 64, (True, True)),     # BASELINE configs[4]: one rank's block of an 8-rank transform of n = 2^27
+    (16, 8, 32, (False, False)),   # rows of 2^8: single-pass row transforms -> the two-step form
+    (24, 8, 2, (False, False)),    # two rows of 2^16: three-step latency shapes on both sides
+])
+def test_slab_rows_fused_equals_relayout_plus_transform(ta, log_n, parts, rows, expect_fused):
+    """toyni_ntt_slab_rows_device (round 5): the relayout folded into the row transforms' addressing gives, bit for bit, what
+    toyni_ntt_slab_relayout_device + toyni_ntt_device give (those two are pinned on the oracle by the tests above), in both directions;
+    and the call reports which form ran."""
+    import ctypes
+    import torch
+    lib = ta._lib.lib
+    dev = torch.device("cuda", 0)
+    n = 1 << log_n
+    big = ta.ntt.get_or_create_ctx(n)
+    m1 = lib.toyni_ntt_ctx_first_pass_points(big.handle)
+    s1 = n // m1
+    row = ta.ntt.get_or_create_ctx(s1)
+    row0 = m1 - rows                                  # the last block of rows: the largest twiddle exponents
+    g = torch.Generator(device="cpu").manual_seed(log_n * 100 + parts)
+    src = torch.randint(0, oracle.P, (rows * s1,), dtype=torch.int32, generator=g).to(dev)
+    for inverse in (0, 1):
+        a, want, got = src.clone(), torch.empty_like(src), torch.empty_like(src)
+        if not inverse:
+            assert lib.toyni_ntt_slab_relayout_device(big.handle, a.data_ptr(), want.data_ptr(), rows, row0, parts, 0, None) == 0
+            assert lib.toyni_ntt_device(row.handle, want.data_ptr(), want.data_ptr(), rows, 0, None) == 0
+        else:
+            assert lib.toyni_ntt_device(row.handle, a.data_ptr(), a.data_ptr(), rows, 1, None) == 0
+            assert lib.toyni_ntt_slab_relayout_device(big.handle, a.data_ptr(), want.data_ptr(), rows, row0, parts, 1, None) == 0
+        b = src.clone()
+        fused = ctypes.c_int(-1)
+        assert lib.toyni_ntt_slab_rows_device(big.handle, row.handle, b.data_ptr(), got.data_ptr(), rows, row0, parts, inverse, ctypes.byref(fused), None) == 0
+        torch.cuda.synchronize()
+        assert bool(fused.value) == expect_fused[inverse], (log_n, parts, rows, inverse, fused.value)
+        assert torch.equal(got, want), f"n=2^{log_n} parts={parts} rows={rows} inverse={inverse}: fused rows differ from relayout + transform"
+        if fused.value and not inverse:
+            assert torch.equal(b, src), "the fused forward form must not touch its input"
+    big.trim()
+    # bad arguments: same buffer both sides, a row context of the wrong size
+    assert lib.toyni_ntt_slab_rows_device(big.handle, row.handle, src.data_ptr(), src.data_ptr(), rows, row0, parts, 0, None, None) == 10006   # TOYNI_E_RANGE
+    assert lib.toyni_ntt_slab_rows_device(big.handle, big.handle, src.data_ptr(), got.data_ptr(), rows, row0, parts, 0, None, None) == 10006   # TOYNI_E_RANGE

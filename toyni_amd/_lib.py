@@ -90,6 +90,7 @@ SIGNATURES = {
     "toyni_first_pass_points": (c_size, [c_u32]),
     "toyni_ntt_slab_pass_device": (c_int, [c_void_p, c_void_p, c_size, c_size, c_int, c_void_p]),
     "toyni_ntt_slab_relayout_device": (c_int, [c_void_p, c_void_p, c_void_p, c_size, c_size, c_size, c_int, c_void_p]),
+    "toyni_ntt_slab_rows_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_size, c_size, c_int, ctypes.POINTER(c_int), c_void_p]),
     "toyni_ntt_slab_multi_gpu_device": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_void_p, c_int, c_int]),
     "toyni_ntt_slab_multi_gpu_host": (c_int, [c_void_p, c_int, c_u32, c_void_p, c_int, c_int]),
     # section 3

@@ -13,7 +13,8 @@
 //                                        single-GPU users of this library never pay for it, and a process that already holds an
 //                                        RCCL (PyTorch) shares that copy by SONAME.
 // The multi-PROCESS form of the same algorithm (one rank per GPU, torch.distributed / RCCL all-to-all) is toyni_amd/dist.py;
-// both drive the same device entry points (toyni_ntt_slab_pass_device, toyni_ntt_slab_relayout_device, toyni_ntt_device).
+// both drive the same device entry points (toyni_ntt_slab_pass_device, toyni_ntt_slab_rows_device -- the relayout folded into the
+// row transforms' addressing where the pass shapes allow it, toyni_ntt_slab_relayout_device + toyni_ntt_device otherwise).
 #pragma once
 #include <dlfcn.h>
 
@@ -378,9 +379,8 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
                 SlabLane& L = g->lanes[h];
                 uint32_t* part = d_rows[h] + q * rq * g->s1;
                 if (h == 0 && phases) MG_PHASE(g, 2, false);   // behind the stream's waits for its incoming blocks: the exchange has landed
-                MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg + q * G * piece, part, rq, h * r + q * rq, G, 0, L.stream));
-                if (h == 0 && phases) MG_PHASE(g, 3, false);
-                MG_TRY(toyni_ntt_device(L.row, part, part, rq, 0, L.stream));
+                if (h == 0 && phases) MG_PHASE(g, 3, false);   // (round 5: no relayout sweep -- the row transforms' first pass reads the pieces)
+                MG_TRY(toyni_ntt_slab_rows_device(L.big, L.row, L.d_xchg + q * G * piece, part, rq, h * r + q * rq, G, 0, nullptr, L.stream));
                 if (h == 0 && phases) MG_PHASE(g, 4, false);
             }
         }
@@ -390,9 +390,9 @@ int slab_run_pieces(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_r
                 SlabLane& L = g->lanes[h];
                 uint32_t* part = d_rows[h] + q * rq * g->s1;
                 if (h == 0 && phases) MG_PHASE(g, 0, true);
-                MG_TRY(toyni_ntt_device(L.row, part, part, rq, 1, L.stream));
+                // inverse size-S1 transforms whose last pass writes the outgoing pieces, times w_n^-(k1 j') (no relayout sweep)
+                MG_TRY(toyni_ntt_slab_rows_device(L.big, L.row, part, L.d_xchg + q * G * piece, rq, h * r + q * rq, G, 1, nullptr, L.stream));
                 if (h == 0 && phases) MG_PHASE(g, 1, true);
-                MG_TRY(toyni_ntt_slab_relayout_device(L.big, part, L.d_xchg + q * G * piece, rq, h * r + q * rq, G, 1, L.stream));
                 if (h == 0 && phases) MG_PHASE(g, 2, true);
                 DeviceGuard guard(L.device);
                 MG_TRY(hipEventRecord(L.ready, L.stream));   // re-recorded per piece: the waits below capture this recording
@@ -440,18 +440,16 @@ int slab_run(SlabGroup* g, uint32_t* const* d_slabs, uint32_t* const* d_rows, bo
         for (size_t h = 0; h < G; ++h) {
             SlabLane& L = g->lanes[h];
             if (h == 0) MG_PHASE(g, 2, false);   // the grouped send / recv run in stream order: behind them
-            MG_TRY(toyni_ntt_slab_relayout_device(L.big, L.d_xchg, d_rows[h], r, h * r, G, 0, L.stream));  // pieces -> rows [r][S1]
-            if (h == 0) MG_PHASE(g, 3, false);
-            MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 0, L.stream));                         // size-S1 transforms over j'
+            if (h == 0) MG_PHASE(g, 3, false);   // (round 5: no relayout sweep)
+            MG_TRY(toyni_ntt_slab_rows_device(L.big, L.row, L.d_xchg, d_rows[h], r, h * r, G, 0, nullptr, L.stream));   // pieces -> size-S1 transforms over j'
             if (h == 0) MG_PHASE(g, 4, false);
         }
     } else {
         for (size_t h = 0; h < G; ++h) {
             SlabLane& L = g->lanes[h];
             if (h == 0) MG_PHASE(g, 0, true);
-            MG_TRY(toyni_ntt_device(L.row, d_rows[h], d_rows[h], r, 1, L.stream));                         // inverse size-S1, scaled by 1/S1
+            MG_TRY(toyni_ntt_slab_rows_device(L.big, L.row, d_rows[h], L.d_xchg, r, h * r, G, 1, nullptr, L.stream));   // inverse size-S1 (1/S1), x w_n^-(k1 j'), into pieces
             if (h == 0) MG_PHASE(g, 1, true);
-            MG_TRY(toyni_ntt_slab_relayout_device(L.big, d_rows[h], L.d_xchg, r, h * r, G, 1, L.stream));  // x w_n^-(k1 j'), rows -> pieces
             if (h == 0) MG_PHASE(g, 2, true);
         }
         MG_TRY(slab_exchange(g, blk, exchange, [&](size_t h) { return g->lanes[h].d_xchg; }, [&](size_t a) { return d_slabs[a]; }));

@@ -67,6 +67,19 @@ struct PassArgs {
     // the n >> LZ leading (nonzero) words of every transform (toyni_lde_device).  nz_rows = input rows that exist.
     uint32_t in_prefix_log;
     uint32_t nz_rows;
+    // ---- the pieces layout around the exchange of a multi-device transform (toyni_ntt_slab_rows_device, round 5) ----
+    // A rank's block of rows (size-S_1 transforms over j') travels as [parts][rows][W], W = S_1 / parts: piece g holds the columns
+    // j' in [g W, (g + 1) W) of every row.  Instead of a relayout sweep on either side of the exchange, the row transforms address it
+    // directly:
+    //   KIND_COL, first pass of the forward row transforms: input row r of a tile belongs to piece r >> in_split_shift, and every
+    //     piece index adds in_split_extra WORDS to the linear address (in_prefix_log = log2 W); 0 = contiguous rows
+    //   KIND_ROW_T, last pass of the inverse row transforms: output sub-index k of a tile belongs to piece k >> out_split_shift,
+    //     out_split_extra words per piece index, transforms 2^out_prefix_log words apart (0 = log_n: contiguous rows); and with
+    //     cs_mode = 4 the output kk of row b is multiplied by w_N^-((row0 + b) kk) -- the twiddle between the row transforms and the
+    //     closing column transforms of the mirrored algorithm -- from the big context's inverse domain table in cs_lo / cs_hi.
+    uint32_t in_split_shift, in_split_extra;
+    uint32_t out_split_shift, out_split_extra, out_prefix_log;
+    uint32_t row0;
 };
 
 // Diagnostic builds only (-DTOYNI_ABLATE=1|2|3, never the shipped library): bit 0 replaces tile loads by register
@@ -222,6 +235,7 @@ struct Pass {
         uint32_t col0;                      // KIND_COL: first column index j' of the tile
         uint32_t out0;                      // in-transform index of output (c = 0, k = 0): KIND_ROW_T k1_0 + mid * M_1, else 0
         uint32_t valid_c;                   // KIND_ROW_N: rows of this tile that exist
+        uint32_t bidx;                      // KIND_ROW_T: the transform (row of the batch) this tile belongs to
     };
 
     // XCD-aware order: workgroups b and b+8 run on the same XCD (round-robin dispatch), and tiles 2x, 2x+1 share
@@ -239,6 +253,7 @@ struct Pass {
         t.out0 = 0;
         t.valid_c = C;
         t.row_shift = 0;
+        t.bidx = 0;
         if (KIND == KIND_COL) {
             const uint32_t tiles_log = a.log_S - LC;
             const uint64_t prefix = (uint64_t)bid >> tiles_log;
@@ -255,8 +270,9 @@ struct Pass {
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
             t.row_shift = a.log_n - a.log_M1;
             t.in = a.in + (((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM)) << LQ_);
-            t.out = a.out + (((b << a.log_n) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
+            t.out = a.out + (((b << (a.out_prefix_log ? a.out_prefix_log : a.log_n)) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
             t.out0 = k1_0 + (mid << a.log_M1);
+            t.bidx = (uint32_t)b;
         } else {
             const uint64_t row0 = (uint64_t)bid << LC;   // virtual rows (interleaved: Q per batch entry; C is a multiple of Q)
             t.in = a.in + (row0 << LM);
@@ -331,6 +347,17 @@ struct Pass {
             const uint32_t e0 = KIND == KIND_ROW_T ? t.out0 + (c >> LQ_) + (khi << (a.log_n - LM)) : khi;
             r.a_lo = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
             r.a_hi = a.cs_hi[e0 >> a.cs_lowbits];
+        } else if (KIND == KIND_ROW_T && a.cs_mode == 4u) {
+            // slab form, inverse: output kk of row k1 = row0 + (transform index) times w_N^-(k1 kk); consecutive registers of a group
+            // are (1 << LSH) << (log_n - LM) outputs apart, so the running factor is w_N^-(k1 * that) -- per tile, looked up like the seed
+            const uint32_t k1 = a.row0 + t.bidx;
+            const uint32_t mask = (1u << a.cs_lowbits) - 1u;
+            const uint32_t e0 = (t.out0 + (c >> LQ_) + (khi << (a.log_n - LM))) * k1;   // < N <= 2^27
+            const uint32_t eg = (k1 << LSH) << (a.log_n - LM);
+            r.a_lo = a.cs_lo[e0 & mask];
+            r.a_hi = a.cs_hi[e0 >> a.cs_lowbits];
+            r.g_lo = a.cs_lo[eg & mask];
+            r.g_hi = a.cs_hi[eg >> a.cs_lowbits];
         }
         return r;
     }
@@ -344,6 +371,9 @@ struct Pass {
             tw.a0 = mont_mul(r.a_hi, r.a_lo);
             if (KIND == KIND_ROW_N && a.scale) tw.a0 = mont_mul(tw.a0, a.scale);  // 1-pass inverse: n^-1 rides along
             tw.g = a.cs_g;
+        } else if (KIND == KIND_ROW_T && a.cs_mode == 4u) {
+            tw.a0 = mont_mul(r.a_hi, r.a_lo);
+            tw.g = mont_mul(r.g_hi, r.g_lo);
         }
         return tw;
     }
@@ -376,6 +406,25 @@ struct Pass {
             for (uint32_t b = 0; b < NB; ++b) {
                 TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
                 if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
+            }
+        } else if (KIND == KIND_ROW_T && a.out_split_extra != 0u) {
+            // slab form, inverse (toyni_ntt_slab_rows_device): the row's outputs go straight into the pieces layout -- sub-index k belongs
+            // to piece k >> out_split_shift, which for register b is a compile-time constant shifted by a uniform amount: the piece
+            // offset joins the store's scalar offset -- and are multiplied by w_N^-(k1 kk) (cs_mode 4) on the way
+            uint32_t tw = twd.a0;
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) {
+                const uint32_t piece = ((b << LSH) >> a.out_split_shift) * (a.out_split_extra << 2);   // store b carries sub-index (b << LSH) | khi
+                uint32_t v = x[cx_bitrev(b, LB)];
+                if (a.cs_mode == 4u) {
+                    v = mont_mul(v, tw);
+                    if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
+                }
+#if TOYNI_BUF
+                stb32<NT_>(ws, off0, b * step + piece, v);
+#else
+                st32<NT_>(reinterpret_cast<uint32_t*>(base + (uint64_t)b * step + piece), off0, v);
+#endif
             }
         } else if (a.cs_mode == 2u) {  // inverse coset transform: * s^k, k = k0 + b * (register step), running product
             uint32_t tw = twd.a0;
@@ -662,6 +711,16 @@ struct Pass {
         const uint32_t step = (in_offset(a, t, 0u, E2) - in_offset(a, t, 0u, 0u)) << 2;
         // register i: (uniform base + i * uniform step) + one per-thread offset -> SGPR pointer math, a single VGPR
         const char* base = reinterpret_cast<const char*>(t.in);
+        if (KIND == KIND_COL && LZ == 0 && a.in_split_extra != 0u) {
+            // slab form, forward (toyni_ntt_slab_rows_device): the tile's rows live in the pieces layout -- row r belongs to piece
+            // r >> in_split_shift (>= LE2 bits, so the piece of register i does not depend on the thread): a uniform term per register
+#pragma unroll
+            for (uint32_t i = I0; i < I1; ++i) {
+                const uint32_t piece = ((i << LE2) >> a.in_split_shift) * (a.in_split_extra << 2);
+                x[i] = ld32<NT_>(reinterpret_cast<const uint32_t*>(base + (uint64_t)i * step + piece), off0);
+            }
+            return;
+        }
         if (live) {
 #if defined(__HIP_DEVICE_COMPILE__)
             // one thread per row (single-step shapes): its E1 words are consecutive -- four per load instead of one (a wave's scalar

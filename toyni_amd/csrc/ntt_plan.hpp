@@ -422,11 +422,26 @@ struct CosetTables {
 // as std::integral_constant; 0 for every other launch).
 // LQ > 0: `batch` counts base-field transforms, Q = 2^LQ of them interleaved word by word (batch = Q x the number of Ext vectors;
 // src / work / dst hold batch * n words in the [vector][element][Q] layout): the interleaved variants of the same passes.
+// The pieces layout around the exchange of a multi-device transform (PassArgs::in_split_* / out_split_*, toyni_ntt_slab_rows_device):
+// the `batch` rows of this call (a rank's block of size-S_1 row transforms) live as [parts][batch][W], W = S_1 / parts, on the exchange
+// side -- read by the FIRST pass of the forward row transforms, written (times w_N^-((row0 + b) kk)) by the LAST pass of the inverse ones.
+// `unsupported` is set, and nothing more is launched, when the shape the dispatch table picks cannot address that layout (three-step
+// shapes, fewer rows per piece than a thread's register stride, a single-pass plan); dry = only that check, no launch at all.
+struct SlabIo {
+    uint32_t log_parts = 0;
+    const uint32_t* tw_lo = nullptr;   // big context's inverse domain table (inverse only)
+    const uint32_t* tw_hi = nullptr;
+    uint32_t tw_lowbits = 0, row0 = 0;
+    bool dry = false;
+    bool* unsupported = nullptr;
+};
+
 template <int LQ = 0, class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
                           uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables(),
-                          int lde_log = 0, bool nt = false) {
+                          int lde_log = 0, bool nt = false, const SlabIo* sio = nullptr) {
     if (plan.log_n == 0 || batch == 0) return true;  // n = 1: identity
+    if (sio && (LQ != 0 || lde_log != 0 || cs.lo || plan.npasses < 2 || (batch & (batch - 1)) != 0 || (int)sio->log_parts >= plan.log_n)) return false;
     if (lde_log && (inverse || plan.npasses < 2 || lde_log > plan.pass[0].log_m)) return false;
     const uint64_t total_log = (uint64_t)plan.log_n;
     for (int p = 0; p < plan.npasses; ++p) {
@@ -472,6 +487,32 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
             uint64_t nblocks;
             if (pp.kind == KIND_ROW_N) nblocks = (batch + P::C - 1) / P::C;
             else nblocks = (batch << (total_log - P::LM)) / P::C;  // tiles of C columns / rows, each M long
+            if (sio) {
+                const uint32_t log_w = (uint32_t)plan.log_n - sio->log_parts;
+                const uint32_t extra = (uint32_t)((batch - 1) << log_w);          // words between two pieces, beyond the W of one row
+                const bool first = p == 0, last = p == plan.npasses - 1;
+                bool ok_shape = true;              // (only the pass that touches the pieces is constrained: the others run as always)
+                if (!inverse && first) {           // forward: the first pass reads the pieces
+                    ok_shape = P::STEPS <= 2 && pp.kind == KIND_COL && pp.log_m >= (int)sio->log_parts + P::IN_STEP_LOG;
+                    a.in_prefix_log = log_w;
+                    a.in_split_shift = (uint32_t)pp.log_m - sio->log_parts;
+                    a.in_split_extra = extra;
+                }
+                if (inverse && last) {             // inverse: the last pass writes them, twiddled
+                    ok_shape = P::STEPS <= 2 && pp.kind == KIND_ROW_T && P::LM >= (int)sio->log_parts + P::OUT_STEP_LOG;
+                    a.out_prefix_log = log_w;
+                    a.out_split_shift = (uint32_t)P::LM - sio->log_parts;
+                    a.out_split_extra = extra;
+                    a.cs_lo = sio->tw_lo;
+                    a.cs_hi = sio->tw_hi;
+                    a.cs_lowbits = sio->tw_lowbits;
+                    a.cs_mode = 4u;
+                    a.row0 = sio->row0;
+                }
+                if (batch == 1) ok_shape = false;  // (one row: extra = 0 would read as "contiguous"; the caller's fallback is exact)
+                if (!ok_shape) { if (sio->unsupported) *sio->unsupported = true; return; }
+                if (sio->dry || (sio->unsupported && *sio->unsupported)) return;
+            }
             launch(pass, lzc, a, nblocks);
         };
         bool ok;

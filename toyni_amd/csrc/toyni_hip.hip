@@ -2041,6 +2041,79 @@ int toyni_ntt_slab_relayout_device(toyni_ntt_ctx* c, const uint32_t* d_in, uint3
     return (int)hipGetLastError();
 }
 
+// Round 5: relayout + row transforms as ONE call, and -- where the dispatched pass shapes can address the pieces layout -- without
+// the relayout sweep: the first pass of the forward row transforms reads [parts][rows][W] directly, the last pass of the inverse ones
+// writes it (twiddled).  Three HBM sweeps per direction around the exchange instead of four.  Shapes that cannot (three-step latency
+// shapes on small launches, fewer rows per piece than a thread's register stride, single-pass row transforms, one row) take the two
+// separate steps: the results are identical either way.  *fused_out (optional): 1 = fused, 0 = the two-step form.
+int toyni_ntt_slab_rows_device(toyni_ntt_ctx* big, toyni_ntt_ctx* row, uint32_t* d_in, uint32_t* d_out, size_t rows_local, size_t row0,
+                               size_t parts, int inverse, int* fused_out, void* stream) {
+    if (fused_out) *fused_out = 0;
+    if (!big || !row || !d_in || !d_out) return TOYNI_E_NULL;
+    if (d_in == d_out) return TOYNI_E_RANGE;
+    const size_t m1 = toyni_ntt_ctx_first_pass_points(big);
+    if (!m1) return TOYNI_E_INVALID_SIZE;
+    const size_t s1 = (size_t)big->n / m1;
+    if (row->n != s1 || row->device != big->device) return TOYNI_E_RANGE;
+    if (!is_pow2(rows_local) || !is_pow2(parts) || parts > s1 || s1 / parts < 32 || row0 + rows_local > m1) return TOYNI_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    bool fused = false;
+    {
+        TOYNI_CTX_LOCK(row);   // (big is only read: its tables are immutable after creation)
+        DeviceGuard guard(row->device);
+        const bool candidate = row->plan.npasses >= 2 && rows_local >= 2 && !lds_kernel_enabled(row->plan, rows_local) &&
+                               !(row->chunk_elems && row->chunk_elems / row->n < rows_local);   // (a chunked context keeps its chunks: two-step form)
+        if (candidate) {
+            SlabIo sio;
+            bool unsupported = false;
+            sio.log_parts = (uint32_t)ilog2(parts);
+            sio.tw_lo = big->d_inv + big->plan.dom_lo_off;
+            sio.tw_hi = big->d_inv + big->plan.dom_hi_off;
+            sio.tw_lowbits = big->plan.dom_lowbits;
+            sio.row0 = (uint32_t)row0;
+            sio.unsupported = &unsupported;
+            sio.dry = true;
+            const uint32_t* tables = inverse ? row->d_inv : row->d_fwd;
+            auto nothing = [](auto, auto, const PassArgs&, uint64_t) {};
+            const bool nt = row->plan.log_n >= 8 && (uint64_t)rows_local * row->n * sizeof(uint32_t) >= nt_min_bytes();
+            bool ok = for_each_pass<0>(row->plan, tables, inverse != 0, d_in, nullptr, d_out, rows_local, nothing, CosetTables(), 0, nt, &sio);
+            if (ok && !unsupported) {
+                toyni_ntt_ctx::Scratch& sc = scratch_for(row, s);
+                int rc = grow(row, s, (void**)&sc.d_work, &sc.work_words, rows_local * (size_t)row->n, sizeof(uint32_t));
+                if (rc) return rc;
+                sio.dry = false;
+                hipError_t err = hipSuccess;
+                int pass_index = 0;
+                auto launch = [&](auto pass, auto lzc, const PassArgs& a, uint64_t nblocks) {
+                    using P = decltype(pass);
+                    constexpr int LZ = decltype(lzc)::value;
+                    const int p = pass_index++;
+                    if (err != hipSuccess) return;
+                    TOYNI_PASS_TIMER(row, s, inverse ? 1 : 0, p);
+                    launch_pass<P, LZ>(persistent_grid<P, LZ>(row, nblocks), s, a, (uint32_t)nblocks);
+                    err = hipGetLastError();
+                };
+                ok = for_each_pass<0>(row->plan, tables, inverse != 0, d_in, sc.d_work, d_out, rows_local, launch, CosetTables(), 0, nt, &sio);
+                if (!ok || unsupported) return TOYNI_E_INVALID_SIZE;   // cannot happen after the dry run said yes
+                if (err != hipSuccess) return (int)err;
+                fused = true;
+            }
+        }
+    }
+    if (fused) {
+        if (fused_out) *fused_out = 1;
+        return TOYNI_OK;
+    }
+    // the two-step form (each call locks the context it uses)
+    int rc;
+    if (!inverse) {
+        if ((rc = toyni_ntt_slab_relayout_device(big, d_in, d_out, rows_local, row0, parts, 0, stream))) return rc;
+        return toyni_ntt_device(row, d_out, d_out, rows_local, 0, stream);
+    }
+    if ((rc = toyni_ntt_device(row, d_in, d_in, rows_local, 1, stream))) return rc;
+    return toyni_ntt_slab_relayout_device(big, d_in, d_out, rows_local, row0, parts, 1, stream);
+}
+
 // ---- domain points (the xs of fri_fold, the evaluation points of the prover) ----
 int toyni_domain_elements_device(toyni_ntt_ctx* c, uint32_t* d_out, size_t m, uint32_t shift, void* stream) {
     if (!c || !d_out) return TOYNI_E_NULL;

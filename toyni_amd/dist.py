@@ -160,6 +160,20 @@ class HipLocalOps:
         check(lib.toyni_ntt_slab_relayout_device(self.big.handle, src.data_ptr(), dst.data_ptr(), rows, row0, parts, int(inverse), stream or None),
               "slab relayout failed")
 
+    def slab_rows(self, src: torch.Tensor, dst: torch.Tensor, rows: int, row0: int, parts: int, inverse: bool) -> None:
+        """Relayout + size-S1 row transforms as one step (toyni_ntt_slab_rows_device): forward pieces -> transformed rows, inverse rows ->
+        inverse-transformed, twiddled pieces.  Where the launch's pass shapes allow it there is no relayout sweep at all (the row
+        transforms address the pieces layout directly); `last_rows_fused` says which form ran.  The inverse form may overwrite src."""
+        import ctypes
+        from ._lib import check, lib
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.int32 and src.numel() == dst.numel()
+        s1 = src.numel() // rows
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fused = ctypes.c_int(0)
+        check(lib.toyni_ntt_slab_rows_device(self.big.handle, self._ctx_for(s1).handle, src.data_ptr(), dst.data_ptr(), rows, row0, parts,
+                                             int(inverse), ctypes.byref(fused), stream or None), "slab rows failed")
+        self.last_rows_fused = bool(fused.value)
+
 
 class PhaseClock:
     """Optional per-phase timing of the multi-device forms (bench.py): `mark(name)` records a HIP event on the device's current stream
@@ -280,9 +294,13 @@ def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
     if chunks <= 1:
         recv = _exchange(slab.view(world, r, w), group)  # row block h (k1 in rank h's chunk) is contiguous: no packing
         _mark(clock, "exchange")
-        ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
-        _mark(clock, "relayout")
-        ops.ntt_rows(rows, False)                  # what is left: size-S1 transforms over j'
+        if hasattr(ops, "slab_rows"):              # (round 5) one step: the row transforms read the [G][r][w] pieces directly -- no relayout sweep
+            _mark(clock, "relayout")
+            ops.slab_rows(recv, rows, r, rank * r, world, False)
+        else:
+            ops.relayout(recv, rows, r, rank * r, world, False)   # [G][r][w] pieces -> contiguous rows [r][S1]
+            _mark(clock, "relayout")
+            ops.ntt_rows(rows, False)              # what is left: size-S1 transforms over j'
         _mark(clock, "row_transforms")
         return rows
     assert chunks & (chunks - 1) == 0 and r % chunks == 0, "chunks must be a power of two dividing the rows per rank"
@@ -297,8 +315,11 @@ def slab_forward(slab: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
         for wk in works:
             wk.wait()
         part = rows[q * rq:(q + 1) * rq]
-        ops.relayout(recv_q, part, rq, rank * r + q * rq, world, False)
-        ops.ntt_rows(part, False)
+        if hasattr(ops, "slab_rows"):
+            ops.slab_rows(recv_q, part, rq, rank * r + q * rq, world, False)
+        else:
+            ops.relayout(recv_q, part, rq, rank * r + q * rq, world, False)
+            ops.ntt_rows(part, False)
     _mark(clock, "exchange_relayout_rows_pipelined")
     return rows
 
@@ -312,10 +333,14 @@ def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
     assert rows.shape == (r, s1) and rows.is_contiguous()
     _mark(clock, "start")
     if chunks <= 1:
-        ops.ntt_rows(rows, True)                   # inverse size-S1 over k', scaled by 1/S1
-        _mark(clock, "row_transforms")
         send = torch.empty((world, r, w), dtype=rows.dtype, device=rows.device)
-        ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
+        if hasattr(ops, "slab_rows"):              # (round 5) one step: the last pass of the inverse row transforms writes the twiddled pieces
+            ops.slab_rows(rows, send, r, rank * r, world, True)
+            _mark(clock, "row_transforms")
+        else:
+            ops.ntt_rows(rows, True)               # inverse size-S1 over k', scaled by 1/S1
+            _mark(clock, "row_transforms")
+            ops.relayout(rows, send, r, rank * r, world, True)    # rows -> [G][r][w] pieces, times w_n^-(k1 j')
         _mark(clock, "relayout")
         slab = _exchange(send, group).view(m1, w)  # block g = k1 in rank g's chunk: the [M1][w] slab
         _mark(clock, "exchange")
@@ -327,9 +352,12 @@ def slab_inverse(rows: torch.Tensor, log_n: int, ops, rank: int = 0, world: int 
         works, keep = [], []
         for q in range(chunks):
             part = rows[q * rq:(q + 1) * rq]
-            ops.ntt_rows(part, True)
             send_q = torch.empty((world, rq, w), dtype=rows.dtype, device=rows.device)
-            ops.relayout(part, send_q, rq, rank * r + q * rq, world, True)
+            if hasattr(ops, "slab_rows"):
+                ops.slab_rows(part, send_q, rq, rank * r + q * rq, world, True)
+            else:
+                ops.ntt_rows(part, True)
+                ops.relayout(part, send_q, rq, rank * r + q * rq, world, True)
             works += _exchange_blocks_async(list(send_q.unbind(0)), [sv[g, q] for g in range(world)], rank, world, group)
             keep.append(send_q)                    # alive until the sends have completed
         for wk in works:
