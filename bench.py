@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--probe-ranks", action="store_true",
                     help="launch check without a GPU: the ranks rendezvous over gloo, count themselves and exit (tests/test_bench_launch.py)")
     ap.add_argument("--exchange", choices=["peer", "rccl"], default="peer", help="slab-sp workload: how the one exchange moves its blocks")
+    ap.add_argument("--slab-phases-child", action="store_true", help=argparse.SUPPRESS)   # internal: bench_slab_single_process's per-phase child
     ap.add_argument("--workload", choices=["batch", "fourstep", "slab", "slab-sp"], default="batch",
                     help="batch: the default sharded batch (weak scaling); fourstep: ONE transform of n = 2^log-n split over "
                          "the ranks with one all-to-all (BASELINE configs[4]; use --log-n 27, the field's limit); slab-sp: the same "
@@ -300,6 +301,47 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def slab_phases_child(args):
+    """Child of bench_slab_single_process: the same lanes through the MEASUREMENT build only (libtoyni_hip_tools.so), lane 0's stream
+    carrying an event between the four stages of every transform; prints {"slab_phases": {...} | null} and nothing else on stdout."""
+    import ctypes
+    import torch
+    import __graft_entry__ as entry
+    from toyni_amd import dist as tdist   # (slab_split only; this process never calls the product library)
+    lanes = args.gpus
+    one_dev = os.environ.get("TOYNI_BENCH_LANES_ON_ONE_DEVICE") == "1" or torch.cuda.device_count() < lanes
+    devices = [0] * lanes if one_dev else list(range(lanes))
+    n = 1 << args.log_n
+    exchange = 1 if args.exchange == "rccl" else 0   # TOYNI_EXCHANGE_RCCL / TOYNI_EXCHANGE_PEER_COPY (include/toyni_hip.h)
+    tl = ctypes.CDLL(entry.build_tools())
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    tl.toyni_ntt_slab_multi_gpu_device.argtypes = [vp, ci, ctypes.c_uint32, vp, vp, ci, ci]
+    tl.toyni_tools_slab_phases_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
+    slabs, rows = [], []
+    for g, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x51AB + g)
+        slabs.append(torch.randint(0, P, (n // lanes,), dtype=torch.int32, device=dev, generator=gen))
+        rows.append(torch.empty(n // lanes, dtype=torch.int32, device=dev))
+    before = [t.clone() for t in slabs]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    devs_c, slabs_c, rows_c = (ci * lanes)(*devices), (vp * lanes)(*[t.data_ptr() for t in slabs]), (vp * lanes)(*[t.data_ptr() for t in rows])
+    run = lambda inv: tl.toyni_ntt_slab_multi_gpu_device(devs_c, lanes, n, slabs_c, rows_c, inv, exchange)
+    phases, psteps = None, 3
+    ok = run(0) == 0 and run(1) == 0 and tl.toyni_tools_slab_phases(1) == 0      # warm: contexts and buffers
+    for _ in range(psteps):
+        ok = ok and run(0) == 0 and run(1) == 0
+    ms, cnt = (ctypes.c_float * 4)(), ctypes.c_uint(0)
+    ok = ok and tl.toyni_tools_slab_phases_read(ms, ctypes.byref(cnt)) == 0 and tl.toyni_tools_slab_phases(0) == 0
+    ok = ok and all(torch.equal(a, b) for a, b in zip(slabs, before))          # the round trips left the data as it was
+    if ok and cnt.value == 2 * psteps:
+        phases = {k: ms[i] / psteps for i, k in enumerate(("slab_pass", "exchange", "relayout", "row_transforms"))}
+    print(json.dumps({"slab_phases": phases}), flush=True)
+    return 0 if ok else 1
+
+
 def bench_slab_single_process(args):
     """ONE process, --gpus devices: the slab transform behind the C ABI (include/toyni_hip.h 2c).  With fewer devices than lanes
     (TOYNI_BENCH_LANES_ON_ONE_DEVICE=1, e.g. the 1-GPU box) every lane sits on device 0 and the exchange is a local copy."""
@@ -354,30 +396,23 @@ def bench_slab_single_process(args):
         assert verified, "multi-device forward transform differs from the single-device transform"
         del nat
     # where a step's time goes: three more steps through the measurement build of the same source, whose lane 0 carries an event
-    # between the four stages (toyni_tools_slab_phases; one-piece exchanges only)
+    # between the four stages (toyni_tools_slab_phases; one-piece exchanges only) -- in a CHILD process: the measured
+    # process never holds a second copy of the library with its own contexts, exchange buffers and communicators, and nothing that
+    # goes wrong there (build, out of memory, RCCL start-up) can take the already measured line down with it
     phases = None
     try:
-        import ctypes
-        tl = ctypes.CDLL(entry.build_tools())
-        vp, ci = ctypes.c_void_p, ctypes.c_int
-        tl.toyni_ntt_slab_multi_gpu_device.argtypes = [vp, ci, ctypes.c_uint32, vp, vp, ci, ci]
-        tl.toyni_tools_slab_phases_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint)]
-        devs_c, slabs_c, rows_c = (ci * lanes)(*devices), (vp * lanes)(*sp), (vp * lanes)(*rp)
-        run = lambda inv: tl.toyni_ntt_slab_multi_gpu_device(devs_c, lanes, n, slabs_c, rows_c, inv, exchange)
-        before = [t.clone() for t in slabs]         # (the verification above left the forward pass's output in the slabs)
-        assert run(0) == 0 and run(1) == 0          # warm: this build's own contexts and buffers
-        assert tl.toyni_tools_slab_phases(1) == 0
-        psteps = 3
-        for _ in range(psteps):
-            assert run(0) == 0 and run(1) == 0
-        ms, cnt = (ctypes.c_float * 4)(), ctypes.c_uint(0)
-        assert tl.toyni_tools_slab_phases_read(ms, ctypes.byref(cnt)) == 0 and tl.toyni_tools_slab_phases(0) == 0
-        if cnt.value == 2 * psteps:
-            phases = {k: ms[i] / psteps for i, k in enumerate(("slab_pass", "exchange", "relayout", "row_transforms"))}
-        assert all(torch.equal(a, b) for a, b in zip(slabs, before)), "round trip through the measurement build changed the data"
-        del before
-    except (OSError, AttributeError) as exc:       # no measurement build: the line goes out without the per-phase times
-        print(f"bench.py: per-phase times unavailable ({exc})", file=sys.stderr)
+        import subprocess
+        slabs.clear(); rows.clear(); keep.clear()      # this process's buffers are no longer needed: the child allocates its own
+        torch.cuda.empty_cache()
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "slab-sp", "--slab-phases-child", "--log-n", str(log_n),
+                              "--gpus", str(lanes), "--exchange", args.exchange], capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith('{"slab_phases"')]
+        if res.returncode == 0 and line:
+            phases = json.loads(line[-1])["slab_phases"]
+        else:
+            print(f"bench.py: per-phase times unavailable (child status {res.returncode}): {res.stderr[-400:]}", file=sys.stderr)
+    except Exception as exc:                        # the line goes out without the per-phase times
+        print(f"bench.py: per-phase times unavailable ({type(exc).__name__}: {exc})", file=sys.stderr)
     pci = {}
     for d in sorted(set(devices)):
         pr = torch.cuda.get_device_properties(d)
@@ -569,6 +604,8 @@ def committed_counters(log_n, batch, dom_is_last_pass, n, t_fwd_s):
 def main():
     args = parse()
     if args.workload == "slab-sp":
+        if args.slab_phases_child:
+            sys.exit(slab_phases_child(args))
         return bench_slab_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))

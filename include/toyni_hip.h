@@ -359,10 +359,12 @@ int toyni_stream_synchronize(toyni_ntt_ctx* ctx, void* stream);   /* hipStreamSy
 int toyni_ntt_ctx_trim(toyni_ntt_ctx* ctx);                       /* hipDeviceSynchronize, then frees every intermediate buffer of the context */
 /* Stream capture: a warm context only enqueues kernels, so its device-resident calls can be captured into a HIP graph.  One caveat:
  * after a context has outgrown or evicted an intermediate buffer, the next call on it that finds the buffer's event complete frees it
- * (hipFree: a device-wide synchronisation, illegal under a GLOBAL-mode capture).  The library skips that sweep while any stream the
- * context has carried is capturing, and runs it in relaxed mode on the calling thread; a global-mode capture that ANOTHER thread has
- * open on a stream this context has never seen is not visible to it.  Callers that capture on several threads use
- * hipStreamCaptureModeThreadLocal / Relaxed, or call toyni_ntt_ctx_trim (or a blocking entry point) before they start capturing. */
+ * (hipFree: a device-wide synchronisation, illegal under a GLOBAL-mode capture).  The library skips that sweep while a stream the
+ * CURRENT call enqueued on (or the context's own stream) is capturing, and runs it in relaxed mode on the calling thread; it never asks
+ * about streams of earlier calls (the caller may have destroyed them since), so a global-mode capture that another thread has open on
+ * some other stream is not visible to it.  Callers that capture on several threads use hipStreamCaptureModeThreadLocal / Relaxed, or
+ * call toyni_ntt_ctx_trim (or a blocking entry point) before they start capturing.  A stream the context has carried may be destroyed
+ * at any time; calling toyni_stream_synchronize(ctx, stream) first also releases what the context kept for it. */
 int toyni_set_device(int device);
 /* Diagnostics: the symbols (one per line) of every kernel this process has launched through the library so far.  Returns the bytes
  * needed including the terminating 0; (NULL, 0) asks for the size.  An in-memory list only: the library writes no file and reads no

@@ -75,7 +75,7 @@ PROFILES = {
 }
 # environment of the child program for each profile (tests/test_gpu_dispatch_matrix.py)
 PROFILE_ENV = {
-    "nt": {"TOYNI_NT_MIN_BYTES": "0", "TOYNI_FOLD_NT_MIN_BYTES": "0", "TOYNI_FOLD_SHAPE": "0"},
+    "nt": {"TOYNI_NT_MIN_BYTES": "0", "TOYNI_FOLD_NT_MIN_BYTES": "0"},
     "two_step": {"TOYNI_P3_TILES": "-1"},
     "two_step_nt": {"TOYNI_P3_TILES": "-1", "TOYNI_NT_MIN_BYTES": "0"},
     "wide": {"TOYNI_P3_TILES": "-1", "TOYNI_WIDE_TILES": "0"},

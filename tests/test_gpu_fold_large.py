@@ -2,8 +2,9 @@
 fold tests (layers up to 2^21) never reach them.
 
   fri_fold_stream_kernel<true,1024,2>    structured points, m * 4 B >= TOYNI_FOLD_NT_MIN_BYTES (256 MiB)          -> m = 2^26, 2^27
-  fri_fold_xs16_kernel<NT,256>           explicit points, half >= 2^21, whole quads, 16-byte aligned pointers      -> m = 2^22 (+ a ragged
-                                         last chunk), 2^24; the non-temporal twin from m * 4 B >= 256 MiB         -> m = 2^26
+  fri_fold_xs16_kernel<NT,256>           explicit points, half >= 2^18 (toyni_fri_fold_xs_device's gate), whole quads, 16-byte aligned
+                                         pointers -> m = 2^19 + 8, 2^22 (+ a ragged last chunk), 2^24; the non-temporal twin
+                                         from m * 4 B >= 256 MiB -> m = 2^26
   fri_fold_ext_stream_kernel<true,...>   Ext values, m * 16 B >= 256 MiB                                          -> m = 2^25
 
 Every output of every layer is compared with the oracle's fri_fold / fri_fold_ext (src/math/fri.rs:27-48, :7-25) -- bit-exact.

@@ -10,5 +10,5 @@ K="" run TOYNI_P3_TILES=-1 TOYNI_WIDE_TILES=0
 K="" run TOYNI_LAT_TILES=-1
 K="not take_the_single_sweep_kernel and not both_executors" run TOYNI_NO_LDS_KERNEL=1
 K="" run TOYNI_LDS_MAX_LOG=15 TOYNI_LDS_MIN_ELEMS=0
-K="not stream_kernel and not xs16_vs_oracle" run TOYNI_FOLD_SHAPE=0 TOYNI_FOLD_XS16=0 TOYNI_FOLD_NT_MIN_BYTES=0
+K="not stream_kernel and not xs16_vs_oracle" run TOYNI_FOLD_XS16=0 TOYNI_FOLD_NT_MIN_BYTES=0
 K="" run TOYNI_MERKLE_COOP_LOG=-1 TOYNI_FENCE=always

@@ -320,6 +320,7 @@ struct SlabPhaseRec {
     struct Rec { hipEvent_t e[5]; bool inverse; };
     std::vector<Rec> recs;
     Rec cur{};
+    SlabGroup* cur_group = nullptr;   // the group whose transform `cur` belongs to: one transform at a time is recorded
     int device = 0;
 };
 inline SlabPhaseRec& slab_phase_rec() { static SlabPhaseRec r; return r; }
@@ -329,9 +330,25 @@ inline void slab_phase_mark(SlabGroup* g, int k, bool inverse) {
     if (!pr.on) return;
     SlabLane& L = g->lanes[0];
     DeviceGuard guard(L.device);
-    if (k == 0) { pr.cur = SlabPhaseRec::Rec{}; pr.cur.inverse = inverse; pr.device = L.device; }
-    if (hipEventCreate(&pr.cur.e[k]) != hipSuccess || hipEventRecord(pr.cur.e[k], L.stream) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (k == 4) pr.recs.push_back(pr.cur);
+    if (k == 0) {
+        // a transform that left through MG_TRY between two marks never reached k == 4: its events are released here, not leaked
+        for (int j = 0; j < 5; ++j) if (pr.cur.e[j]) (void)hipEventDestroy(pr.cur.e[j]);
+        pr.cur = SlabPhaseRec::Rec{};
+        pr.cur.inverse = inverse;
+        pr.cur_group = g;
+        pr.device = L.device;
+    }
+    if (pr.cur_group != g) return;   // another group's transform is being recorded: its marks are not mixed into this record
+    if (hipEventCreate(&pr.cur.e[k]) != hipSuccess) { pr.cur.e[k] = nullptr; (void)hipGetLastError(); return; }
+    if (hipEventRecord(pr.cur.e[k], L.stream) != hipSuccess) { (void)hipEventDestroy(pr.cur.e[k]); pr.cur.e[k] = nullptr; (void)hipGetLastError(); return; }
+    if (k == 4) {
+        bool complete = true;
+        for (int j = 0; j < 5; ++j) complete = complete && pr.cur.e[j] != nullptr;
+        if (complete) pr.recs.push_back(pr.cur);   // only records with all five events are read back
+        else for (int j = 0; j < 5; ++j) if (pr.cur.e[j]) (void)hipEventDestroy(pr.cur.e[j]);
+        pr.cur = SlabPhaseRec::Rec{};
+        pr.cur_group = nullptr;
+    }
 }
 #define MG_PHASE(g, k, inverse) slab_phase_mark((g), (k), (inverse))
 #else

@@ -1142,9 +1142,16 @@ void finish_call(toyni_ntt_ctx* c) {
     for (auto& kv : c->scratch) any_dirty |= kv.second.dirty;
     if (!any_dirty && !fresh && c->retired.empty()) return;
     DeviceGuard guard(c->device);
+    // streams KNOWN to be alive: the ones this very call enqueued on, and the context's own.  Only those are asked whether they are
+    // capturing below -- a key of c->scratch may be a stream its owner has destroyed since (querying a stale handle is
+    // undefined, and a recycled handle could block the sweep for ever or wrongly allow it)
+    hipStream_t live[MAX_SCRATCH_STREAMS + 1];
+    size_t nlive = 0;
+    live[nlive++] = c->stream;
     for (auto& kv : c->scratch) {
         toyni_ntt_ctx::Scratch& sc = kv.second;
         if (!sc.dirty) continue;
+        if (kv.first != c->stream && nlive < MAX_SCRATCH_STREAMS + 1) live[nlive++] = kv.first;
         sc.dirty = false;
         sc.fenced = false;
         // a set that holds real memory is fenced in single-stream use too: its calls are long (the event is noise next to them) and
@@ -1178,12 +1185,12 @@ void finish_call(toyni_ntt_ctx* c) {
     (void)hipGetLastError();   // hipErrorNotReady from the queries is not an error
     if (!any_ready) return;
     // hipFree synchronises the device and is illegal while a global-mode capture is open.  Relaxed mode below covers THIS thread; a
-    // capture that another thread has open on one of this context's streams is visible here, and then the sweep waits for a later
-    // call.  What cannot be seen -- a global-mode capture on a stream this context has never carried -- is the caveat
-    // documented in include/toyni_hip.h: capture with hipStreamCaptureModeThreadLocal / Relaxed, or call toyni_ntt_ctx_trim first.
-    for (auto& kv : c->scratch) {
+    // capture open on a stream THIS call used (or on the context's own stream) is visible here, and then the sweep waits for a later
+    // call.  What cannot be seen -- a global-mode capture on any other stream -- is the caveat documented in
+    // include/toyni_hip.h: capture with hipStreamCaptureModeThreadLocal / Relaxed, or call toyni_ntt_ctx_trim first.
+    for (size_t i = 0; i < nlive; ++i) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(kv.first, &cap) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipStreamIsCapturing(live[i], &cap) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (cap != hipStreamCaptureStatusNone) return;
     }
     hipStreamCaptureMode cmode = hipStreamCaptureModeRelaxed;
@@ -2139,11 +2146,6 @@ static uint64_t fold_nt_min_bytes() {
     return v;
 }
 
-static int fold_shape() {
-    static const int v = [] { const char* e = std::getenv("TOYNI_FOLD_SHAPE"); return e ? std::atoi(e) : 2; }();
-    return v;
-}
-
 static int fold_args(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_out, size_t m, uint32_t beta, uint32_t x0, FoldArgs& f) {
     if (m % 2) return TOYNI_E_ODD_LENGTH;
     if (!is_pow2(m) || m > c->n) return TOYNI_E_RANGE;
@@ -2170,19 +2172,18 @@ static int enqueue_fold(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_t* d_o
     if (d_leaves) {
         hipLaunchKernelGGL((fri_fold_kernel<false, true>), dim3(grid_for(work)), dim3(256), 0, s, f, reinterpret_cast<const uint4*>(d_salts),
                            reinterpret_cast<Digest*>(d_leaves));
-    } else if ((f.half & 3) == 0 && m >= 64 && (uint64_t)m * sizeof(uint32_t) >= fold_nt_min_bytes() && fold_shape() != 0) {
+    } else if ((f.half & 3) == 0 && m >= 64 && (uint64_t)m * sizeof(uint32_t) >= fold_nt_min_bytes()) {
         // layers beyond the Infinity Cache (>= 256 MiB of input): the shaped stream, 1024 threads x 2 load pairs in flight, non-temporal.
         // A cache-resident 2^24 layer is 5 % FASTER on the 256-thread kernel below (5.95 against 5.63 TB/s), so smaller layers keep it.
-        // TOYNI_FOLD_SHAPE=0 (A/B knob): round 2's kernel.  Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt):
-        // 5.45-5.47 TB/s for the round-2 kernel, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 /
-        // 1024 x 2 / 512 x 4 -- only the winner is instantiated.  (Round 4: the gate was 2^26 elements with the non-temporal hint from
+        // Measured on a 2^27 layer, alternating (profiles/r03_ab_fold_shape.txt): 5.45-5.47 TB/s for round 2's 256-thread kernel with
+        // non-temporal accesses, 5.83 for its shape with fold_quad (256 x 4), 5.72 / 6.01-6.19 / 5.93 for 1024 x 4 / 1024 x 2 / 512 x 4
+        // -- only the winner is instantiated (round 5: the A/B knob TOYNI_FOLD_SHAPE and the non-temporal twin of the 256-thread
+        // kernel, which nothing but that knob could reach on a layer of more than 32 elements, are gone: ADVICE r4).  (Round 4: the gate was 2^26 elements with the non-temporal hint from
         // 512 MiB only, so a 2^26 layer streamed with plain accesses: 76 -> 67 us with the hint, tools/foldsweep.py.)
         const uint64_t quads = f.half / 4, chunk = 1024 * 2, cap = (uint64_t)c->num_cus * 8;
         uint64_t g = (quads + chunk - 1) / chunk;
         if (g > cap) g = cap;
         hipLaunchKernelGGL((fri_fold_stream_kernel<true, 1024, 2>), dim3((unsigned)g), dim3(1024), 0, s, f);
-    } else if ((uint64_t)m * sizeof(uint32_t) >= fold_nt_min_bytes()) {
-        hipLaunchKernelGGL((fri_fold_kernel<true, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     } else {
         hipLaunchKernelGGL((fri_fold_kernel<false, false>), dim3(grid_for(work)), dim3(256), 0, s, f, no_salts, no_leaves);
     }
@@ -2289,7 +2290,7 @@ int toyni_fri_fold_ext_device(toyni_ntt_ctx* c, const uint32_t* d_evals, uint32_
     // streaming layers (>= TOYNI_FOLD_NT_MIN_BYTES = 256 MiB of input): the shaped stream, 5.0-5.2 -> 6.0 TB/s on a 2^25-element layer,
     // 5.2 -> 5.9 on a 2^24-element one (256 MiB in, 128 MiB out: past the Infinity Cache); a cache-resident 2^22-element layer is faster
     // on the 256-thread kernel (6.2 against 4.8 TB/s: profiles/r03_ab_fold_ext_shape.txt)
-    if ((uint64_t)m * 16 >= fold_nt_min_bytes() && fold_shape() != 0) {
+    if ((uint64_t)m * 16 >= fold_nt_min_bytes()) {
         const uint64_t chunk = 2 * 1024, cap = (uint64_t)c->num_cus * 8;
         uint64_t g = (fa.base.half + chunk - 1) / chunk;
         if (g > cap) g = cap;
