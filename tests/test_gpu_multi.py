@@ -487,6 +487,8 @@ def test_stream_plumbing_for_hosts_without_a_hip_binding(ta):
 
 
 @pytest.mark.parametrize("log_n,parts,rows,expect_fused", [
+    (21, 2, 64, (True, True)),     # rows of 2^14 = 128 x 128: the 128-point column and closing shapes
+    (24, 2, 128, (True, True)),    # rows of 2^16 = 256 x 256: the 256-point column and closing shapes
     (22, 2, 128, (True, True)),    # 128-point first pass, rows of 2^15 = 128 x 256: two-step shapes on both sides
     (22, 2, 64, (True, False)),    # half as many rows: the closing 256-point pass of the inverse takes its three-step latency shape -> two-step form
     (26, 8, 32, (True, True)),     # configs[4]'s shapes one size down: rows of 2^18 = 512 x 512 (the (5,4) column and closing shapes)

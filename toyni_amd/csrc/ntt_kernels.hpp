@@ -165,8 +165,15 @@ constexpr uint32_t cx_bitrev(uint32_t x, int bits) {
 // column is (column >> LQ) (the host passes log_S / in_prefix_log inflated by LQ); the row kinds run C "virtual rows"
 // c = (row << LQ) | q per tile, lanes running over (q, position) so that loads and stores stay contiguous, and park virtual row c
 // in LDS row rho(c) (coordinate-major within blocks of 8 rows: conflict-free for both the step-1 writes and the step-2 reads).
-template <int KIND, int LE1, int LE2, int LC, bool NT_ = false, int LQ_ = 0>
+// SLAB_ (round 5): the variant of a shape that addresses the PIECES layout of a multi-device transform (PassArgs::in_split_* /
+// out_split_*, toyni_ntt_slab_rows_device).  A compile-time variant, not a run-time branch: an alternating A/B of the round-4 library
+// against one with those branches inside every kernel read +0.5 % at 1024 x 2^20 and +3 % at 4096 x 2^18 (profiles/r05_ab_lib.txt) --
+// the ordinary kernels must not know the layout exists.
+template <int KIND, int LE1, int LE2, int LC, bool NT_ = false, int LQ_ = 0, bool SLAB_ = false>
 struct Pass {
+    static constexpr bool SLAB = SLAB_;
+    static constexpr int PASS_KIND = KIND;
+    static_assert(!SLAB_ || ((KIND == KIND_COL || KIND == KIND_ROW_T) && LQ_ == 0 && LE2 > 0), "pieces layout: two-step column / closing passes of base-field rows");
     static_assert(LE2 <= LE1 && LE1 <= 5 && LE1 >= 1, "step sizes");
     static constexpr int LQ = LQ_;
     static constexpr uint32_t Q = 1u << LQ_;
@@ -270,9 +277,9 @@ struct Pass {
             const uint64_t b = (uint64_t)bid >> (a.log_mid + k1_tiles_log);
             t.row_shift = a.log_n - a.log_M1;
             t.in = a.in + (((b << a.log_n) + ((uint64_t)k1_0 << t.row_shift) + ((uint64_t)mid << LM)) << LQ_);
-            t.out = a.out + (((b << (a.out_prefix_log ? a.out_prefix_log : a.log_n)) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
+            t.out = a.out + (((b << (SLAB_ ? a.out_prefix_log : a.log_n)) + k1_0 + ((uint64_t)mid << a.log_M1)) << LQ_);
             t.out0 = k1_0 + (mid << a.log_M1);
-            t.bidx = (uint32_t)b;
+            if (SLAB_) t.bidx = (uint32_t)b;
         } else {
             const uint64_t row0 = (uint64_t)bid << LC;   // virtual rows (interleaved: Q per batch entry; C is a multiple of Q)
             t.in = a.in + (row0 << LM);
@@ -347,7 +354,7 @@ struct Pass {
             const uint32_t e0 = KIND == KIND_ROW_T ? t.out0 + (c >> LQ_) + (khi << (a.log_n - LM)) : khi;
             r.a_lo = a.cs_lo[e0 & ((1u << a.cs_lowbits) - 1u)];
             r.a_hi = a.cs_hi[e0 >> a.cs_lowbits];
-        } else if (KIND == KIND_ROW_T && a.cs_mode == 4u) {
+        } else if (SLAB_ && KIND == KIND_ROW_T && a.cs_mode == 4u) {
             // slab form, inverse: output kk of row k1 = row0 + (transform index) times w_N^-(k1 kk); consecutive registers of a group
             // are (1 << LSH) << (log_n - LM) outputs apart, so the running factor is w_N^-(k1 * that) -- per tile, looked up like the seed
             const uint32_t k1 = a.row0 + t.bidx;
@@ -371,7 +378,7 @@ struct Pass {
             tw.a0 = mont_mul(r.a_hi, r.a_lo);
             if (KIND == KIND_ROW_N && a.scale) tw.a0 = mont_mul(tw.a0, a.scale);  // 1-pass inverse: n^-1 rides along
             tw.g = a.cs_g;
-        } else if (KIND == KIND_ROW_T && a.cs_mode == 4u) {
+        } else if (SLAB_ && KIND == KIND_ROW_T && a.cs_mode == 4u) {
             tw.a0 = mont_mul(r.a_hi, r.a_lo);
             tw.g = mont_mul(r.g_hi, r.g_lo);
         }
@@ -407,7 +414,7 @@ struct Pass {
                 TOYNI_STORE(b, mont_mul(x[cx_bitrev(b, LB)], tw));
                 if (b + 1 < NB) { tw = mont_mul_lazy(tw, twd.g); TOYNI_PIN(tw); }
             }
-        } else if (KIND == KIND_ROW_T && a.out_split_extra != 0u) {
+        } else if (SLAB_ && KIND == KIND_ROW_T) {
             // slab form, inverse (toyni_ntt_slab_rows_device): the row's outputs go straight into the pieces layout -- sub-index k belongs
             // to piece k >> out_split_shift, which for register b is a compile-time constant shifted by a uniform amount: the piece
             // offset joins the store's scalar offset -- and are multiplied by w_N^-(k1 kk) (cs_mode 4) on the way
@@ -711,7 +718,7 @@ struct Pass {
         const uint32_t step = (in_offset(a, t, 0u, E2) - in_offset(a, t, 0u, 0u)) << 2;
         // register i: (uniform base + i * uniform step) + one per-thread offset -> SGPR pointer math, a single VGPR
         const char* base = reinterpret_cast<const char*>(t.in);
-        if (KIND == KIND_COL && LZ == 0 && a.in_split_extra != 0u) {
+        if (SLAB_ && KIND == KIND_COL && LZ == 0) {
             // slab form, forward (toyni_ntt_slab_rows_device): the tile's rows live in the pieces layout -- row r belongs to piece
             // r >> in_split_shift (>= LE2 bits, so the piece of register i does not depend on the thread): a uniform term per register
 #pragma unroll

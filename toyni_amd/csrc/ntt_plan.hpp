@@ -436,6 +436,17 @@ struct SlabIo {
     bool* unsupported = nullptr;
 };
 
+// the SLAB variant of a two-step shape (Pass<..., SLAB_ = true>); only the 32-wide plain shapes have one (see slab_variant_exists)
+template <class P> struct SlabVariant { using type = P; };
+template <int K, int A, int B, int C, bool N, int Q> struct SlabVariant<Pass<K, A, B, C, N, Q, false>> { using type = Pass<K, A, B, C, false, Q, true>; };
+// The pieces layout is addressed by the 128-, 256- and 512-point column and closing shapes in their 32-wide, plain (not non-temporal)
+// form: the row transforms of a multi-device transform are 2^14 .. 2^18 points (n = 2^21 .. 2^27, M1 = 2^7 .. 2^9), and one rank's
+// launch is far below the footprint / tile counts from which the wide and non-temporal twins are picked.  Six kernels, not forty.
+template <class P> constexpr bool slab_variant_exists() {
+    if constexpr (P::STEPS == 2) return P::PASS_KIND != KIND_ROW_N && P::LQ == 0 && P::C == 32u && P::LM >= 7 && P::LM <= 9 && !P::NT;
+    else return false;
+}
+
 template <int LQ = 0, class Launch>
 inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src,
                           uint32_t* work, uint32_t* dst, uint64_t batch, Launch&& launch, const CosetTables& cs = CosetTables(),
@@ -492,14 +503,15 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
                 const uint32_t extra = (uint32_t)((batch - 1) << log_w);          // words between two pieces, beyond the W of one row
                 const bool first = p == 0, last = p == plan.npasses - 1;
                 bool ok_shape = true;              // (only the pass that touches the pieces is constrained: the others run as always)
+                const bool special = (!inverse && first) || (inverse && last);
                 if (!inverse && first) {           // forward: the first pass reads the pieces
-                    ok_shape = P::STEPS <= 2 && pp.kind == KIND_COL && pp.log_m >= (int)sio->log_parts + P::IN_STEP_LOG;
+                    ok_shape = slab_variant_exists<P>() && pp.kind == KIND_COL && pp.log_m >= (int)sio->log_parts + P::IN_STEP_LOG;
                     a.in_prefix_log = log_w;
                     a.in_split_shift = (uint32_t)pp.log_m - sio->log_parts;
                     a.in_split_extra = extra;
                 }
                 if (inverse && last) {             // inverse: the last pass writes them, twiddled
-                    ok_shape = P::STEPS <= 2 && pp.kind == KIND_ROW_T && P::LM >= (int)sio->log_parts + P::OUT_STEP_LOG;
+                    ok_shape = slab_variant_exists<P>() && pp.kind == KIND_ROW_T && P::LM >= (int)sio->log_parts + P::OUT_STEP_LOG;
                     a.out_prefix_log = log_w;
                     a.out_split_shift = (uint32_t)P::LM - sio->log_parts;
                     a.out_split_extra = extra;
@@ -512,12 +524,18 @@ inline bool for_each_pass(const NttPlan& plan, const uint32_t* tables, bool inve
                 if (batch == 1) ok_shape = false;  // (one row: extra = 0 would read as "contiguous"; the caller's fallback is exact)
                 if (!ok_shape) { if (sio->unsupported) *sio->unsupported = true; return; }
                 if (sio->dry || (sio->unsupported && *sio->unsupported)) return;
+                if constexpr (slab_variant_exists<P>() && decltype(lzc)::value == 0) {
+                    if (special) { launch(typename SlabVariant<P>::type{}, lzc, a, nblocks); return; }
+                }
             }
             launch(pass, lzc, a, nblocks);
         };
         bool ok;
+        // the pass that touches the pieces layout of a slab launch takes its 32-wide plain shape (the only ones with a SLAB variant)
+        const bool slab_special = sio && ((!inverse && p == 0) || (inverse && p == plan.npasses - 1));
+        if (slab_special && log_tiles32 >= wide_min_log_tiles32()) log_tiles32 = wide_min_log_tiles32() - 1;
         if (p == 0 && lde_log) ok = dispatch_pass_lz<LQ>(pp.log_m, log_tiles32, lde_log < 5 ? lde_log : 5, body);
-        else ok = dispatch_pass<LQ>(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); }, nt);
+        else ok = dispatch_pass<LQ>(pp.kind, pp.log_m, log_tiles32, [&](auto pass) { body(pass, std::integral_constant<int, 0>{}); }, nt && !slab_special);
         if (!ok) return false;
     }
     return true;

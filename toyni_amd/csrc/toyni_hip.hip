@@ -78,7 +78,7 @@ inline bool note(const void* host_fn) {
 //     behind them -- all of it BEFORE the current tile's stores, in flight across the barrier and the whole of step 2.
 // The barriers are raw s_barrier with an explicit LDS-only wait: __syncthreads() would also drain vmcnt.
 template <class P> struct PassKindOf;
-template <int K, int A, int B, int C, bool N, int Q> struct PassKindOf<Pass<K, A, B, C, N, Q>> { static constexpr int value = K; };
+template <int K, int A, int B, int C, bool N, int Q, bool S> struct PassKindOf<Pass<K, A, B, C, N, Q, S>> { static constexpr int value = K; };
 template <class P> constexpr int kind_of() { return PassKindOf<P>::value; }
 
 // LZ > 0: first pass of a low-degree extension -- the input holds only the leading n >> LZ words of every transform
