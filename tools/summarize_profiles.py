@@ -53,7 +53,7 @@ traffic = {"log_n": log_n, "batch_per_gpu": batch, "command": f"python3 bench.py
            "timing_command": f"python3 bench.py --log-n {log_n} --batch {batch} --no-extras --no-cpu-baseline (default --steps 20 --warmup 3): rocprof_avg_ns",
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", "kernels": {}}
 for k, v in allc.items():
-    if "ntt_pass_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    if ("ntt_pass_kernel" in k or "ntt_pass3s_kernel" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:   # (the streaming passes; not the latency shapes of lone transforms)
         traffic["kernels"][k] = {
             "fetch_size_kib_raw": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"],
             "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
