@@ -994,6 +994,49 @@ def main():
         }
         c24.destroy()
 
+        # ---- n = 2^21, the prover's own LDE size (configs[2]), batched: 128 transforms (1 GiB).  Round 5: TWO sweeps (1024-point
+        #      column pass + the streaming three-step 2048-point closing pass) where rounds 1-4 made three 128-point ones
+        c21b = toyni_amd.NttContext(1 << 21, device=dev.index)
+        n21, b21 = 1 << 21, 128
+        buf21 = data[: n21 * b21] if data.numel() >= n21 * b21 else torch.randint(0, P, (n21 * b21,), dtype=torch.int32, device=dev)
+        p21 = buf21.data_ptr()
+
+        def fb21():
+            c21b.run_device(p21, p21, b21, False, stream=stream)
+            c21b.run_device(p21, p21, b21, True, stream=stream)
+
+        t21 = time_dev(fb21, 5)
+        extras["batched_n2^21"] = {"batch": b21, "ms_per_fwd_inv": t21 * 1e3, "elements_per_s": 2 * b21 * n21 / t21,
+                                   "passes_per_transform": c21b.passes_for(b21),
+                                   "note": "same step as `value` at n = 2^21; the three-pass plan of rounds 1-4: 2.70 ms (1.99e11 elements/s)"}
+        tl21 = ToolsLib(entry.build_tools())
+        th21 = tl21.context(n21, dev.index)
+        tl21.run(th21, p21, b21, False, stream)
+        tl21.run(th21, p21, b21, True, stream)
+
+        def steps21():
+            for _ in range(5):
+                tl21.run(th21, p21, b21, False, stream)
+                tl21.run(th21, p21, b21, True, stream)
+
+        r21 = tl21.timed_region(th21, steps21, b21)
+        tl21.destroy(th21)
+        f21, i21 = r21["forward"], r21["inverse"]
+        np21 = len(f21)
+        d21 = max(range(np21), key=lambda p: f21[p] + i21[p])
+        d21_ms = 0.5 * (f21[d21] + i21[d21])
+        alg21 = 8.0 * n21 * b21 / np21
+        tr21, tr21_src, _ = committed_counters(21, b21, np21 > 1 and d21 == np21 - 1, n21, sum(f21) * 1e-3)
+        extras["batched_n2^21"]["roofline"] = {
+            "bound": "hbm", "achieved": alg21 / (d21_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg21 / (d21_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": tr21, "traffic_source": tr21_src,
+            "kernel": f"pass {d21} of {np21} ({'ntt_pass3s_kernel, the streaming 2048-point closing pass' if d21 == np21 - 1 else 'ntt_pass_kernel, the 1024-point column pass'})",
+            "kernel_ms": d21_ms, "algorithmic_bytes_per_launch": alg21, "all_pass_ms": {"forward": f21, "inverse": i21},
+            "kernel_stream_GBps": 8.0 * n21 * b21 / (d21_ms * 1e-3) / 1e9,
+            "transform_algorithmic_GBps": 8.0 * n21 * b21 / (sum(f21) * 1e-3) / 1e9,
+        }
+        c21b.destroy()
+
         # ---- low-degree extension of a batch of columns (src/fibonacci.rs:101-103, blowup 32, coset shift 7): zero padding
         #      implied (toyni_lde_device) vs padded by hand + the ordinary coset transform
         l_out, l_blow, l_batch = 21, 5, 64
