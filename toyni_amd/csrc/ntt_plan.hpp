@@ -42,8 +42,10 @@ struct NttPlan {
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
 
-// latency = true: the second plan of n = 2^21 / 2^22, two passes (2048-point three-step shapes exist only as 4-wide latency
-// tiles): one launch fewer for a lone transform; streaming launches keep the three-pass split below
+// latency = true: the SECOND plan of n = 2^21 / 2^22, two passes with a 2048-point three-step pass.  Rounds 2-4: 4-wide latency tiles
+// only -- one launch fewer for a lone transform -- while streaming launches kept the three-pass split below.  Round 5: the 2048-point
+// pass also has a STREAMING shape (16-wide tiles, 32 elements per thread), so n = 2^21 runs this plan for launches of every size
+// (has_stream2_plan), n = 2^22 for lone transforms and for its low-degree extensions (toyni_hip.hip: use_two_pass_plan)
 // (n = 2^23 / 2^24 as 4096-point three-step passes were built and measured too: 54.6 against 50.7 us and 124 against 88 us for the
 // three-pass plan -- a 4096 x 4 tile is one 1024-thread workgroup per CU with 16-byte row segments; not kept)
 inline bool has_latency_plan(int log_n) { return log_n == 21 || log_n == 22; }
@@ -274,12 +276,13 @@ inline int& stream3_min_log_tiles32() {
 inline bool has_stream2_plan(int log_n) { return log_n == 21; }
 
 // LQ > 0: the interleaved (Ext, AoS) variants: the same table (a lone Ext vector counts as four transforms' worth of tiles), without
-// the 8-wide two-step shapes and the 2048-point latency plans.
+// the 8-wide two-step shapes and the 2048-point latency and column shapes (the streaming 2048-point CLOSING pass has its interleaved form).
 template <int LQ = 0, class F>
 inline bool dispatch_pass(int kind, int log_m, int log_tiles32, F&& f, bool nt = false) {
     // measured crossover (profiles/r02_latency.txt): 2^6 32-wide tiles for the 1024-point shapes, 2^7 for the 512-point and 2^8
     // for the 256-point ones (8 elements per thread: lighter, they win up to larger launches)
-    // 2048-point passes exist only in the latency plans of n = 2^21 / 2^22 and only as three-step shapes
+    // 2048-point passes exist only in the two-pass plans of n = 2^21 / 2^22 and only as three-step shapes (4-wide latency tiles here; the
+    // 16-wide streaming closing pass above)
     // the streaming 2048-point closing pass (base and interleaved form; a lone Ext vector is already 2^7 32-wide tiles' worth at n = 2^21)
     if (log_m == 11 && kind == KIND_ROW_T && log_tiles32 >= stream3_min_log_tiles32()) {
         if (nt) f(Pass3<KIND_ROW_T, 5, 3, 3, 4, true, LQ>{}); else f(Pass3<KIND_ROW_T, 5, 3, 3, 4, false, LQ>{});
