@@ -135,3 +135,73 @@ def test_plain_2p22_keeps_the_three_pass_plan_and_lone_transforms_the_latency_sh
     assert ctx21.passes_for(1) == 2 and ctx21.passes_for(1024) == 2
     ctx13 = ta.ntt.get_or_create_ctx(1 << 13)
     assert ctx13.passes == 2 and ctx13.passes_for(1) == 2 and ctx13.passes_for(1 << 12) == 1    # the single-sweep kernel from 2^25 elements
+
+
+def test_random_shapes_on_the_two_pass_plans(ta):
+    """Seeded differential fuzz over the sizes with a second plan (n = 2^21, 2^22): batches either side of the 2^7-tile gate, both
+    directions, coset shifts, in place / out of place, chunked launches, low-degree extensions of every blow-up, Ext vectors at 2^21.
+    TOYNI_FUZZ_SEED / TOYNI_FUZZ_CASES: soak runs (default: the fixed 14 cases of every session).  Every transform against the oracle."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("TOYNI_FUZZ_SEED", str(0x2B21)), 0))
+    for case in range(int(os.environ.get("TOYNI_FUZZ_CASES", "14"))):
+        log_n = 21 + int(rng.integers(0, 2))
+        n = 1 << log_n
+        kind = int(rng.integers(0, 4))                      # 0, 1: plain / coset transform; 2: LDE; 3: Ext (2^21) or LDE (2^22)
+        shift = 1 if rng.integers(0, 3) == 0 else int(rng.integers(2, P))
+        ctx = ta.ntt.get_or_create_ctx(n)
+        if kind <= 1:
+            batch = int(rng.integers(1, 7 if log_n == 21 else 4))
+            inverse, inplace = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            chunk = None if rng.integers(0, 3) else int(n * rng.integers(1, batch + 1))
+            x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+            if chunk:
+                ctx.set_chunk(chunk)
+            a = DevBuf(ta, x.nbytes)
+            b = a if inplace else DevBuf(ta, x.nbytes)
+            try:
+                a.upload(x)
+                ctx.run_device(a.ptr, b.ptr, batch, inverse, shift=shift)
+                ctx.synchronize()
+                y = b.download(np.uint32, x.size)
+            finally:
+                ctx.set_chunk(0)
+                a.free()
+                if b is not a:
+                    b.free()
+            for t in range(batch):
+                row = x[t * n:(t + 1) * n].astype(np.uint64)
+                want = oracle.domain_ifft(row, shift) if inverse else oracle.domain_fft(row, n, shift)
+                assert (y[t * n:(t + 1) * n] == want).all(), f"case {case}: 2^{log_n} x{batch} inverse={inverse} shift={shift} inplace={inplace} chunk={chunk} t={t}"
+        elif kind == 2 or log_n == 22:
+            z = int(rng.integers(1, 13))
+            batch = int(rng.integers(1, 6 if log_n == 21 else 4))
+            n_in = n >> z
+            c = rng.integers(0, P, size=n_in * batch, dtype=np.uint32)
+            a, b = DevBuf(ta, c.nbytes), DevBuf(ta, 4 * n * batch)
+            try:
+                a.upload(c)
+                ctx.lde_device(a.ptr, b.ptr, batch, z, shift)
+                ctx.synchronize()
+                y = b.download(np.uint32, n * batch)
+            finally:
+                a.free()
+                b.free()
+            for t in range(batch):
+                want = oracle.domain_fft(c[t * n_in:(t + 1) * n_in].astype(np.uint64), n, shift)
+                assert (y[t * n:(t + 1) * n] == want).all(), f"case {case}: LDE 2^{log_n - z} -> 2^{log_n} x{batch} shift={shift} t={t}"
+        else:
+            vecs, inverse = int(rng.integers(1, 3)), bool(rng.integers(0, 2))
+            x = rng.integers(0, P, size=(vecs, n, 4), dtype=np.uint32)
+            a = DevBuf(ta, x.nbytes)
+            try:
+                a.upload(x)
+                ctx.run_device_ext_batch(a.ptr, a.ptr, vecs, inverse, shift=shift)
+                ctx.synchronize()
+                y = a.download(np.uint32, x.size).reshape(x.shape)
+            finally:
+                a.free()
+            for v in range(vecs):
+                k = int(rng.integers(0, 4))
+                col = np.ascontiguousarray(x[v, :, k]).astype(np.uint64)
+                want = oracle.domain_ifft(col, shift) if inverse else oracle.domain_fft(col, n, shift)
+                assert (y[v, :, k] == want).all(), f"case {case}: Ext 2^21 x{vecs} inverse={inverse} shift={shift} vector {v} coordinate {k}"
