@@ -184,8 +184,8 @@ def run_matrix(ta, oracle, profile="default", log=print):
                 for batch in ([1, 4, 16] if (full and log_n == 20) else [1, 16] if full and log_n < 20 else [1, 4] if full else [1]):
                     check_lde(log_n, batch, z, 7, False)
                     ncases += 1
-                if cfg["ext"] and log_n <= 20:
-                    for vecs in ([1, 4] if full else [1]):
+                if cfg["ext"] and log_n <= 22:   # (2^21 / 2^22: the interleaved streaming 2048-point shapes, a lone vector)
+                    for vecs in ([1, 4] if full and log_n <= 20 else [1]):
                         check_lde(log_n, vecs, z, 7, True)
                         ncases += 1
             if log_n <= 16:   # a blow-up beyond five bits (the LZ = 5 variant with its row guard) and one beyond the first pass (pad + transform)

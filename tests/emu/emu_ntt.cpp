@@ -154,7 +154,7 @@ static void test_coset(int log_n, uint64_t batch, uint32_t shift) {
 // compact coefficient vector ([n >> lde_log][4]) with the padding implied.
 static void test_ext(int log_n, uint64_t vectors, uint32_t shift, int lde_log = 0) {
     NttPlan plan;
-    CHECK(build_plan(log_n, plan, latency_plan && log_n == 21), "plan %d", log_n);   // "Q1": n = 2^21 through its two-pass plan (streaming closing pass)
+    CHECK(build_plan(log_n, plan, latency_plan && (log_n == 21 || (log_n == 22 && lde_log))), "plan %d", log_n);   // "Q1": 2^21, and the LDE to 2^22, through their two-pass plans
     const size_t n = (size_t)1 << log_n, n_in = n >> lde_log;
     std::vector<uint64_t> ref(4 * n_in * vectors);
     orc_fill_splitmix(ref.data(), ref.size(), 0xE7700ull + (uint64_t)log_n * 131 + (uint64_t)lde_log);

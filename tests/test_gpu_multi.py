@@ -6,6 +6,8 @@
   * context-free host entry points after the staging rewrite (fold, Ext fold, Merkle): repeated calls, zero points."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 
@@ -486,6 +488,10 @@ def test_stream_plumbing_for_hosts_without_a_hip_binding(ta):
     assert lib.toyni_stream_destroy(sa) == 0 and lib.toyni_stream_destroy(sb) == 0 and lib.toyni_stream_destroy(None) == 0
 
 
+def _dispatch_knobs_set():
+    return any(k.startswith("TOYNI_") and k not in ("TOYNI_LAUNCH_LOG", "TOYNI_FUZZ_SEED", "TOYNI_FUZZ_CASES", "TOYNI_LIB_OVERRIDE") for k in os.environ)
+
+
 @pytest.mark.parametrize("log_n,parts,rows,expect_fused", [
     (21, 2, 64, (True, True)),     # rows of 2^14 = 128 x 128: the 128-point column and closing shapes
     (24, 2, 128, (True, True)),    # rows of 2^16 = 256 x 256: the 256-point column and closing shapes
@@ -524,7 +530,8 @@ def test_slab_rows_fused_equals_relayout_plus_transform(ta, log_n, parts, rows, 
         fused = ctypes.c_int(-1)
         assert lib.toyni_ntt_slab_rows_device(big.handle, row.handle, b.data_ptr(), got.data_ptr(), rows, row0, parts, inverse, ctypes.byref(fused), None) == 0
         torch.cuda.synchronize()
-        assert bool(fused.value) == expect_fused[inverse], (log_n, parts, rows, inverse, fused.value)
+        if not _dispatch_knobs_set():   # which form runs is the DEFAULT dispatch's choice; under a dispatch knob (tools/knob_soak.sh) only the results are judged
+            assert bool(fused.value) == expect_fused[inverse], (log_n, parts, rows, inverse, fused.value)
         assert torch.equal(got, want), f"n=2^{log_n} parts={parts} rows={rows} inverse={inverse}: fused rows differ from relayout + transform"
         if fused.value and not inverse:
             assert torch.equal(b, src), "the fused forward form must not touch its input"

@@ -128,7 +128,34 @@ def test_ext_vectors_of_2p21_through_the_two_pass_plan(ta, vectors, shift):
     assert _launched(ta, "ntt_pass3s_kernelIN5toyni5Pass3ILi1ELi5ELi3ELi3ELi4ELb0ELi2E"), "the interleaved streaming closing pass never ran"
 
 
+@pytest.mark.parametrize("z,vectors", [(5, 1), (3, 2)])
+def test_ext_lde_to_2p22_through_the_interleaved_column_shape(ta, z, vectors):
+    """fft_ext of zero-padded Ext coefficient vectors on the LDE coset (src/math/domain.rs:107-123,129-151), 2^(22-z) -> 2^22: the
+    interleaved 16-wide 2048-point column shape (zero-fraction variant) + the interleaved streaming closing pass."""
+    n, n_in = 1 << 22, (1 << 22) >> z
+    rng = np.random.default_rng(0xE22 + z)
+    c = rng.integers(0, P, size=(vectors, n_in, 4), dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    a, b = DevBuf(ta, c.nbytes), DevBuf(ta, 16 * n * vectors)
+    try:
+        a.upload(c)
+        ctx.lde_ext_device(a.ptr, b.ptr, vectors, z, 7)
+        ctx.synchronize()
+        y = b.download(np.uint32, 4 * n * vectors).reshape(vectors, n, 4)
+    finally:
+        a.free()
+        b.free()
+    for v in range(vectors):
+        for k in (range(4) if v == 0 else [2]):
+            want = oracle.domain_fft(np.ascontiguousarray(c[v, :, k]).astype(np.uint64), n, 7)
+            assert (y[v, :, k] == want).all(), f"Ext LDE 2^{22 - z} -> 2^22: vector {v} coordinate {k}"
+    assert any(f"EELi{z}EEv" in k for k in _launched(ta, "ntt_pass3s_kernelIN5toyni5Pass3ILi0ELi5ELi3ELi3ELi4ELb0ELi2E")), "interleaved column shape never ran"
+
+
 def test_plain_2p22_keeps_the_three_pass_plan_and_lone_transforms_the_latency_shapes(ta):
+    import os
+    if any(k.startswith("TOYNI_") and k not in ("TOYNI_LAUNCH_LOG", "TOYNI_FUZZ_SEED", "TOYNI_FUZZ_CASES") for k in os.environ):
+        pytest.skip("the default dispatch's plan choices are asserted only without dispatch knobs (tools/knob_soak.sh)")
     ctx22 = ta.ntt.get_or_create_ctx(1 << 22)
     assert ctx22.passes == 3 and ctx22.passes_for(1) == 2 and ctx22.passes_for(2) == 2 and ctx22.passes_for(64) == 3
     ctx21 = ta.ntt.get_or_create_ctx(1 << 21)

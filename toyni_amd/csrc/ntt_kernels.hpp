@@ -882,8 +882,8 @@ struct Pass {
 template <int KIND, int LE1, int LE2, int LE3, int LC, bool NT_ = false, int LQ_ = 0>
 struct Pass3 {
     static_assert(KIND == KIND_COL || KIND == KIND_ROW_T, "passes of multi-pass plans");
-    static_assert(LQ_ == 0 || (LQ_ == 2 && (LC == 2 || (LC == 4 && KIND == KIND_ROW_T && LE1 == 5))),
-                  "interleaved tiles: one element's four coordinates (latency), or four rows x four coordinates (streaming row shape)");
+    static_assert(LQ_ == 0 || (LQ_ == 2 && (LC == 2 || (LC == 4 && LE1 == 5))),
+                  "interleaved tiles: one element's four coordinates (latency), or four rows / elements x four coordinates (streaming shapes)");
     static constexpr int LQ = LQ_;
     static_assert(LE1 >= LE2 && LE2 >= LE3 && LE3 >= 1 && LE1 <= 5, "step sizes");
     static constexpr int STEPS = 3;

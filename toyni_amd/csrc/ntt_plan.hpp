@@ -381,8 +381,9 @@ inline bool dispatch_pass_lz(int log_m, int log_tiles32, int lz, F&& f) {
         default: return false;                                                               \
     }
 #define TOYNI_COMMA ,
+    // (the interleaved form too: the LDE of Ext vectors to 2^22 points -- a lone vector is 2^8 32-wide tiles' worth)
+    if (log_m == 11 && log_tiles32 >= stream3_min_log_tiles32()) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 4 TOYNI_COMMA false TOYNI_COMMA LQ>) }
     if constexpr (LQ == 0) {
-        if (log_m == 11 && log_tiles32 >= stream3_min_log_tiles32()) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 5 TOYNI_COMMA 3 TOYNI_COMMA 3 TOYNI_COMMA 4>) }
         if (log_m == 11) { TOYNI_LZ_CASES(Pass3<KIND_COL TOYNI_COMMA 4 TOYNI_COMMA 4 TOYNI_COMMA 3 TOYNI_COMMA 2>) }
     }
     if (pass3_max_log_tiles32() >= 0 && log_m >= 8 && log_m <= 10 && log_tiles32 <= pass3_max_log_tiles32() + (10 - log_m)) {

@@ -1339,7 +1339,9 @@ bool use_two_pass_plan(const toyni_ntt_ctx* c, uint64_t batch, int lq, int lde_l
     // Ext (interleaved) vectors: only where BOTH passes have interleaved streaming shapes (n = 2^21: the 1024-point column shapes and
     // the 2048-point closing shape; there are no interleaved 2048-point latency or column shapes).  A lone vector is four transforms'
     // worth of tiles -- 2^7 32-wide ones for the closing pass -- so every launch, chunked or not, reaches the streaming shape.
-    if (lq != 0) return has_stream2_plan(c->plan.log_n) && stream3_min_log_tiles32() <= 7;
+    // (a low-degree extension of Ext vectors to n = 2^22 as well: its first pass is the interleaved 16-wide 2048-point column shape
+    // in its zero-fraction variants, 2^8 tiles' worth per vector)
+    if (lq != 0) return (has_stream2_plan(c->plan.log_n) || (lde_log != 0 && has_latency_plan(c->plan.log_n))) && stream3_min_log_tiles32() <= 7;
     const bool lat_small = pass3_max_log_tiles32() >= 0 && lat_max_log_tiles32() >= 0 &&
                            ((batch << (c->plan.log_n - c->plan_lat.pass[0].log_m)) >> 5) <= (1ull << lat_max_log_tiles32());
     // a low-degree extension reads 2^-lde_log of its first pass's input: the two sweeps win there even where the plain transform's do not
