@@ -72,6 +72,7 @@ static void emu_tile(const PassArgs& a, uint32_t b, uint32_t* lds) {
 }
 
 static uint64_t lde_batch = 2;      // "bN": vectors per low-degree-extension case ("lLOGxZ")
+static bool use_row2048 = false;   // "R1": n = 2^11 through the one-wave-per-transform kernel (Row2048)
 static int lds_rows = 5;      // rows per workgroup of the single-sweep kernel (2^lds_rows)
 static bool use_lds = true;   // sizes 2^11 .. 2^15 have two executors: the single-sweep kernel and the two-pass plan
 // LQ > 0: the interleaved (Ext, AoS) passes -- `batch` counts base-field transforms, 2^LQ of them interleaved word by word
@@ -89,6 +90,27 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         cs.hi = cblob.data() + hi_off;
     }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
+    if (LQ == 0 && use_row2048 && plan.log_n == 11 && !lde_log) {   // one wave per transform: stepped wave by wave, lane by lane within a step
+        bool okr = row2048_transform(plan, blob.data(), inverse, src, dst, batch, [&](const PassArgs& a, uint64_t rows) {
+            using R = Row2048;
+            std::vector<uint32_t> row_lds(R::ROW_WORDS, 0xDEADBEEFu);   // exactly one wave's slice: an overrun is an ASan error
+            std::vector<uint32_t> regs(64 * R::E);
+            for (uint64_t row = 0; row < rows; ++row) {
+                for (uint32_t l = 0; l < 64; ++l) {      // every load of the row before any store (in-place transforms)
+                    uint32_t (&x)[R::E] = *reinterpret_cast<uint32_t (*)[R::E]>(&regs[(size_t)l * R::E]);
+                    R::load_row<false>(a, row, l, x);
+                }
+                for (uint32_t l = 0; l < 64; ++l) {
+                    uint32_t (&x)[R::E] = *reinterpret_cast<uint32_t (*)[R::E]>(&regs[(size_t)l * R::E]);
+                    R::step1(a, l, x, row_lds.data(), R::tw1_global(a), R::tw3_global(a));
+                }
+                for (uint32_t l = 0; l < 64; ++l) R::step2(l, row_lds.data(), R::tw2_global(a));
+                for (uint32_t l = 0; l < 64; ++l) R::step3<false>(a, R::consts(a), row, l, row_lds.data());
+            }
+        }, cs);
+        CHECK(okr, "row2048 transform rejected log_n=%d", plan.log_n);
+        return;
+    }
     if (LQ == 0 && use_lds && plan.lds_la && !lde_log) {      // n = 2^11 .. 2^15: the single-sweep kernel, phase by phase (two barriers)
         bool okl = lds_transform(plan, blob.data(), inverse, src, dst, batch, [&](auto pass, const LdsArgs& g, uint64_t ntiles) {
             using L = decltype(pass);
@@ -660,7 +682,14 @@ int main(int argc, char** argv) {
     test_field();
     std::printf("field ok=%d\n", failures == 0);
     for (int log_n = 0; log_n <= max_log; ++log_n) {
-        if (log_n >= 11 && log_n <= 15) {           // these sizes have two executors: first the two-pass plan ...
+        if (log_n == 11) {                          // n = 2^11: the two-pass plan below, and the one-wave-per-transform kernel (ragged batches, coset)
+            use_row2048 = true;
+            test_ntt(log_n, 1, 0);
+            test_ntt(log_n, 19, 0);
+            test_coset(log_n, 3, 7);
+            use_row2048 = false;
+        }
+        if (log_n >= 12 && log_n <= 15) {           // these sizes have two executors: first the two-pass plan ...
             use_lds = false;
             test_ntt(log_n, 3, 0);
             test_coset(log_n, 2, 7);
@@ -700,6 +729,10 @@ int main(int argc, char** argv) {
         }
         if (argv[i][0] == 'Q') {
             latency_plan = argv[i][1] == '1';
+            continue;
+        }
+        if (argv[i][0] == 'R') {                    // "R1" / "R0": n = 2^11 through the one-wave-per-transform kernel from here on
+            use_row2048 = argv[i][1] == '1';
             continue;
         }
         if (argv[i][0] == 'b') {                    // "bN": vectors per "l" case from here on

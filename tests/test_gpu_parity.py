@@ -669,14 +669,14 @@ def test_shipped_library_has_no_measurement_hooks(ta):
 
 
 def test_both_executors_of_the_single_sweep_sizes(ta):
-    # n = 2^11 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
-    # batches of 2^11 .. 2^13 only).  Force each one for every size, small ragged batches, in child processes (the knobs are
+    # n = 2^12 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
+    # batches of 2^12 / 2^13 only; n = 2^11 has the one-wave-per-transform kernel, tests/test_gpu_stream3.py).  Force each one for every size, small ragged batches, in child processes (the knobs are
     # read once per process); which executor ran is read off the launch records (1 launch per transform vs 2).
     code = (
         "import os, numpy as np, oracle, toyni_amd\n"
         "from test_gpu_parity import DevBuf\n"
         "want_launches = int(os.environ['TOYNI_TEST_LAUNCHES'])\n"
-        "for log_n in range(11, 16):\n"
+        "for log_n in range(12 if want_launches == 1 else 11, 16):   # (n = 2^11 has no LDS-kernel form since round 5: Row2048)\n"
         "    n, batch = 1 << log_n, 5\n"
         "    ctx = toyni_amd.NttContext(n)\n"
         "    x = oracle.splitmix(batch * n, 777 + log_n).astype(np.uint32)\n"

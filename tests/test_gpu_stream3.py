@@ -232,3 +232,38 @@ def test_random_shapes_on_the_two_pass_plans(ta):
                 col = np.ascontiguousarray(x[v, :, k]).astype(np.uint64)
                 want = oracle.domain_ifft(col, shift) if inverse else oracle.domain_fft(col, n, shift)
                 assert (y[v, :, k] == want).all(), f"case {case}: Ext 2^21 x{vecs} inverse={inverse} shift={shift} vector {v} coordinate {k}"
+
+
+@pytest.mark.parametrize("batch,shift,inverse,inplace", [
+    (2048, 1, False, True),       # the smallest batch that takes the kernel (TOYNI_R2048_MIN_ROWS)
+    (5001, 7, False, False),      # ragged: some waves run one row more than others; forward coset, out of place
+    (4099, 1234567, True, True),  # inverse coset (n^-1 rides on the output seeds)
+    (3000, 1, True, False),       # plain inverse: n^-1 at the store
+])
+def test_n2p11_one_wave_per_transform(ta, batch, shift, inverse, inplace):
+    """n = 2^11 (the reference's own test size: trace 64, blow-up 32 -> 2048 points, src/fibonacci.rs tests) in ONE sweep, one wave per
+    transform and no workgroup barrier (Row2048, ntt_row2048_kernel).  EVERY transform of the batch against the oracle."""
+    n = 1 << 11
+    rng = np.random.default_rng(0x2048 + batch)
+    x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+    x[:n] = (7 * np.arange(n, dtype=np.uint64) + 3) % P
+    ctx = ta.ntt.get_or_create_ctx(n)
+    assert ctx.passes == 2 and ctx.passes_for(batch) == 1 and ctx.passes_for(5) == 2
+    a = DevBuf(ta, x.nbytes)
+    b = a if inplace else DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device(a.ptr, b.ptr, batch, inverse, shift=shift)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size)
+        if not inplace:
+            assert (a.download(np.uint32, x.size) == x).all(), "out-of-place transform modified its input"
+    finally:
+        a.free()
+        if b is not a:
+            b.free()
+    rows = x.reshape(batch, n).astype(np.uint64)
+    for t in range(batch):
+        want = oracle.domain_ifft(rows[t], shift) if inverse else oracle.domain_fft(rows[t], n, shift)
+        assert (y[t * n:(t + 1) * n] == want).all(), f"2^11 x{batch} shift {shift} inverse {inverse}: transform {t}"
+    assert _launched(ta, "ntt_row2048_kernel"), "the one-wave-per-transform kernel never ran"

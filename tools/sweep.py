@@ -60,11 +60,9 @@ def main():
             windows.append(a.elapsed_time(b) / reps)
         ms = sorted(windows)[2]
         spread = (max(windows) - min(windows)) / ms
-        # the launcher's rule (toyni_hip.hip: use_lds_kernel, default knobs): plain base transforms of 2^11 .. 2^13 in launches of >= 2^25
-        # elements run the single-sweep LDS kernel instead of the plan's two passes
-        lds = (11 <= log_n <= int(os.environ.get("TOYNI_LDS_MAX_LOG", "13")) and batch * n >= int(os.environ.get("TOYNI_LDS_MIN_ELEMS", 1 << 25))
-               and not lde and not os.environ.get("SWEEP_EXT"))
-        sweeps = 1 if lds else (ctx.passes if (lde or os.environ.get("SWEEP_EXT")) else ctx.passes_for(batch))
+        # one launch per call where the library says so (toyni_ntt_ctx_passes_for: the one-wave-per-transform kernel of 2^11, the single-sweep
+        # LDS kernel of large batches of 2^12 / 2^13, the two-pass plan of 2^21); LDE / Ext forms: the plain plan's count
+        sweeps = ctx.passes if (lde or os.environ.get("SWEEP_EXT")) else ctx.passes_for(batch)
         print(f"n=2^{log_n:<2d} batch={batch:<9d} sweeps={sweeps} {ms:8.4f} ms  {batch * n / ms / 1e6:8.1f} Gelem/s  "
               f"{8.0 * sweeps * batch * n / ms / 1e9:7.2f} TB/s moved  (windows +-{50 * spread:.1f} %)", flush=True)
         if toyni_amd._lib.HAS_TOOLS and os.environ.get("SWEEP_PASSES"):   # TOYNI_LIB_OVERRIDE=.../libtoyni_hip_tools.so

@@ -1367,6 +1367,131 @@ struct LdsPass {
     }
 };
 
+// ---- n = 2^11 in ONE sweep, ONE WAVE per transform (round 5) --------------------------------------------------------------------
+// A 2048-point transform is 32 elements per lane of one wave.  The three register steps of the streaming three-step shape
+// (Pass3<..., 5, 3, 3, ...>) then exchange data only WITHIN the wave, so a row needs no workgroup barrier at all: a wave loads its row
+// (contiguous, 256 bytes per instruction), runs steps 1 / 2 / 3 through its private 2112-word slice of LDS (LDS operations of one wave
+// execute in order) and stores the row in natural order (contiguous again).  The 16 waves of a workgroup share nothing but the
+// step-1 twiddle slices; each walks its own rows with the next row's loads in flight behind the current row's stores.
+//   position r = (a << 6) | (b << 3) | d   a: 5 bits (step 1, registers), b: 3 bits (step 2), d: 3 bits (step 3)
+//   LDS word of position r: r + (r >> 5)  (one pad word per 32), which makes every access of every step conflict-free:
+//     step 1  lane = lo (b, d), registers over a        : words lo + (lo >> 5) + 66 i                  -- consecutive lanes, consecutive words
+//     step 2  lanes over (a & 15, d & 3), registers over b: words 66 a + d + {0, 8, 16, 24, 33, 41, 49, 57}   -- bank 2 a + d: 32 different ones
+//     step 3  lane l <-> hm = (a, b) = 4 l + rev2(g), registers over d: words 33 l + 8 rev2(g) + j         -- bank l
+//   output sub-index of register j of lane l, group g in step 3: k = rev3(j) << 8 | (g << 6) | rev6(l): a wave's store covers 64
+//   consecutive words (in a permuted lane order, which costs nothing).
+// Replaces, for n = 2^11, the single-sweep LdsPass kernel (3.6e11 elements/s: 61 lane-operations per element at 56 % VALU
+// utilisation, three workgroup barriers per tile).
+struct Row2048 {
+    static constexpr int LM = 11;
+    static constexpr uint32_t M = 2048, E = 32, WAVES = 16, T = 64 * WAVES;
+    static constexpr uint32_t ROW_WORDS = M + (M >> 5);
+    static constexpr uint32_t LDS_WORDS = WAVES * ROW_WORDS;
+    static constexpr uint32_t TW1_WORDS = M - 64u;      // stages 6 .. 10 of the packed 2048-point stage table
+    static constexpr uint32_t TW3_WORDS = M - 128u;     // blocks 7 .. 10 of its radix-4 companion
+    using Stg = Pass<KIND_ROW_N, 5, 5, 3>;
+    static TOYNI_HD const uint32_t* tw1_global(const PassArgs& a) { return a.stage_tw + 63u; }
+    static TOYNI_HD const uint32_t* tw3_global(const PassArgs& a) { return a.stage_tw3 + 126u; }
+    static TOYNI_HD uint32_t word(uint32_t r) { return r + (r >> 5); }
+
+    static constexpr uint32_t TW2_WORDS = 56u;          // stages 3 .. 5 (step 2): words [7, 63) of the table
+    static TOYNI_HD const uint32_t* tw2_global(const PassArgs& a) { return a.stage_tw + 7u; }
+    // (the step-2 twiddles live in LDS too and the coset seeds are looked up per row: held in registers for the whole launch they
+    // pushed the kernel to 128 VGPRs + 92 bytes of scratch)
+    struct Consts { uint32_t uni[4]; };   // w_8^q, wave-uniform (SGPRs)
+    static TOYNI_HD uint32_t d_of(uint32_t l, uint32_t g) { return ((l >> 4) & 3u) | ((g >> 1) << 2); }
+    static TOYNI_HD uint32_t a_of(uint32_t l, uint32_t g) { return (l & 15u) | ((g & 1u) << 4); }
+    static TOYNI_HD uint32_t kappa_of(uint32_t l, uint32_t g) { return (g << 6) | bitrev32(l, 6); }
+    static TOYNI_HD Consts consts(const PassArgs& a) {
+        Consts c{};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) c.uni[q] = TOYNI_UNIFORM(a.stage_tw[3u + q]);
+        return c;
+    }
+    template <bool NT>
+    static TOYNI_HD void load_row(const PassArgs& a, uint64_t row, uint32_t l, uint32_t (&x)[E]) {
+        const uint32_t* base = a.in + (row << LM);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) x[i] = ld32<NT>(base + i * 64u, l << 2);
+    }
+    // step 1: coset input scaling, the five high stage bits (radix 4, twiddle slices in LDS), park in the wave's LDS slice
+    static TOYNI_HD void step1(const PassArgs& a, uint32_t l, uint32_t (&x)[E], uint32_t* row_lds, const uint32_t* tw1, const uint32_t* tw3) {
+        if (a.cs_mode == 1u) {   // x[j] *= s^j, j = l + 64 i: the lane's seed s^l, then a running product with s^64
+            uint32_t tw = mont_mul(a.cs_hi[l >> a.cs_lowbits], a.cs_lo[l & ((1u << a.cs_lowbits) - 1u)]);
+#pragma unroll
+            for (uint32_t i = 0; i < E; ++i) {
+                x[i] = mont_mul(x[i], tw);
+                if (i + 1 < E) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
+            }
+        }
+        Stg::template stages<5, 6, true>(x, tw1, l, nullptr, tw3);
+        const uint32_t base = l + (l >> 5);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) row_lds[base + i * 66u] = x[i];
+    }
+    // step 2: the three middle stage bits, in place; twiddles from registers
+    // tw2: words [7, 63) of the packed stage table (stages 3 .. 5): entry (1 << (s + 3)) - 8 + d + 8 q = w_{2^(s+4)}^(d + 8 q)
+    static TOYNI_HD void step2(uint32_t l, uint32_t* row_lds, const uint32_t* tw2) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t d = d_of(l, g);
+            const uint32_t base = 66u * a_of(l, g) + d;
+            uint32_t tw[7];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << s); ++q) tw[(1u << s) - 1u + q] = tw2[(1u << (s + 3)) - 8u + d + (q << 3)];
+            uint32_t x[8];
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) x[b] = row_lds[base + 8u * b + (b >> 2)];
+#pragma unroll
+            for (int s = 2; s >= 0; --s) {
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    if (i & (1u << s)) continue;
+                    const uint32_t w = tw[(1u << s) - 1u + (i & ((1u << s) - 1u))];
+                    const uint32_t u = x[i], v = x[i + (1u << s)];
+                    x[i] = bb_add(u, v);
+                    x[i + (1u << s)] = mont_dot_sub(u, v, w, BB_P - w);
+                }
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) row_lds[base + 8u * b + (b >> 2)] = x[b];
+        }
+    }
+    // step 3: the three low stage bits (uniform twiddles), output scaling, natural-order store
+    template <bool NT>
+    static TOYNI_HD void step3(const PassArgs& a, const Consts& c, uint64_t row, uint32_t l, const uint32_t* row_lds) {
+        uint32_t* out = a.out + (row << LM);
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t base = 33u * l + 8u * cx_bitrev(g, 2);
+            uint32_t x[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) x[j] = row_lds[base + j];
+            Stg::template stages<3, 0>(x, nullptr, 0u, c.uni);
+            const uint32_t kappa = kappa_of(l, g);
+            const uint32_t off0 = kappa << 2;
+            uint32_t tw = 0u;
+            if (a.cs_mode == 2u) {   // X[k] *= s^k, k = (b << 8) | kappa: seed s^kappa (times n^-1), then a running product with s^256
+                tw = mont_mul(a.cs_hi[kappa >> a.cs_lowbits], a.cs_lo[kappa & ((1u << a.cs_lowbits) - 1u)]);
+                if (a.scale) tw = mont_mul(tw, a.scale);
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {   // store b carries output k = (b << 8) | kappa, held by register rev3(b)
+                uint32_t v = x[cx_bitrev(b, 3)];
+                if (a.cs_mode == 2u) {
+                    v = mont_mul(v, tw);
+                    if (b + 1 < 8) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
+                } else if (a.scale) {
+                    v = mont_mul(v, a.scale);
+                }
+                st32<NT>(out + b * 256u, off0, v);
+            }
+        }
+    }
+};
+
 // ---- u64 <-> u32 edge of the reference-shaped entry points (src/ntt.rs:233: &mut [BabyBear] as *mut u64) ----
 // narrow also reduces mod p, so a non-canonical u64 behaves like BabyBear::new (src/babybear.rs:26-30)
 TOYNI_HD uint32_t narrow_u64(uint64_t v) { return (uint32_t)(v % BB_P); }

@@ -296,6 +296,49 @@ __global__ void __launch_bounds__(L::T, 4) ntt_lds_kernel(const LdsArgs g, const
     }
 }
 
+// n = 2^11 in one sweep, one wave per transform (Row2048, ntt_kernels.hpp): no workgroup barrier after the twiddle slices are in LDS.
+// A wave walks rows w, w + (waves in the grid), ...; the next row's 32 loads are issued as soon as step 1 has parked the registers
+// in the wave's LDS slice, ahead of this row's 32 stores, so the counted vmcnt wait at the top retires them while the stores drain.
+template <bool NT>
+__global__ void __launch_bounds__(Row2048::T, 4) ntt_row2048_kernel(const PassArgs a) {
+    using R = Row2048;
+    __shared__ uint32_t lds[R::LDS_WORDS + R::TW1_WORDS + R::TW3_WORDS + R::TW2_WORDS];
+    const uint32_t tid = threadIdx.x, l = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint32_t* lds_tw1 = lds + R::LDS_WORDS;
+    uint32_t* lds_tw3 = lds_tw1 + R::TW1_WORDS;
+    uint32_t* lds_tw2 = lds_tw3 + R::TW3_WORDS;
+    uint32_t* row_lds = lds + wave * R::ROW_WORDS;
+    for (uint32_t j = tid; j < R::TW1_WORDS; j += R::T) lds_tw1[j] = R::tw1_global(a)[j];
+    for (uint32_t j = tid; j < R::TW3_WORDS; j += R::T) lds_tw3[j] = R::tw3_global(a)[j];
+    if (tid < R::TW2_WORDS) lds_tw2[tid] = R::tw2_global(a)[tid];
+    const uint64_t stride = (uint64_t)gridDim.x * R::WAVES;
+    uint64_t row = (uint64_t)blockIdx.x * R::WAVES + wave;
+    uint32_t x[R::E];
+    const bool any = row < a.rows_total;   // wave-uniform
+    if (any) R::template load_row<NT>(a, row, l, x);
+    const R::Consts c = R::consts(a);
+    TOYNI_WAIT_VMEM0();
+    __syncthreads();                       // the twiddle slices: the only data the waves of a workgroup share
+    if (!any) return;
+    while (true) {
+        TOYNI_WAIT_VMEM_ALLOW(R::E);       // this row's loads were issued before the previous row's E stores
+        R::step1(a, l, x, row_lds, lds_tw1, lds_tw3);
+        TOYNI_SCHED_FENCE();
+        const uint64_t next = row + stride;
+        const bool more = next < a.rows_total;  // wave-uniform
+        if (more) R::template load_row<NT>(a, next, l, x);   // prefetch
+        TOYNI_SCHED_FENCE();
+        asm volatile("" ::: "memory");     // steps 2 and 3 read what this wave itself wrote: program order suffices (LDS operations of a wave execute in order)
+        R::step2(l, row_lds, lds_tw2);
+        asm volatile("" ::: "memory");
+        R::template step3<NT>(a, c, row, l, row_lds);
+        if (!more) break;
+        asm volatile("" ::: "memory");
+        row = next;
+    }
+}
+
 __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = narrow_u64(in[i]);
@@ -1235,6 +1278,17 @@ uint64_t lds_min_elems() {
     }();
     return v;
 }
+// n = 2^11: the one-wave-per-transform kernel from TOYNI_R2048_MIN_ROWS transforms up (default 2048 -- measured crossover with the
+// two-pass plan: 19.2 us either way at 2048 rows, 22.0 against 30.1 us at 4096, 0.485 against 0.736 ms at 2^17; 0 = always, a huge
+// value = never: the two-pass plan for every batch)
+uint64_t row2048_min_rows() {
+    static const uint64_t v = [] {
+        const char* env = std::getenv("TOYNI_R2048_MIN_ROWS");
+        return env ? (uint64_t)std::strtoull(env, nullptr, 0) : (uint64_t)2048;
+    }();
+    return v;
+}
+bool row2048_enabled(const NttPlan& plan, uint64_t batch) { return plan.log_n == 11 && batch >= row2048_min_rows() && batch >= 1; }
 bool lds_kernel_enabled(const NttPlan& plan, uint64_t batch) {
     return plan.lds_la != 0 && plan.log_n <= lds_max_log() && (batch << plan.log_n) >= lds_min_elems();
 }
@@ -1376,6 +1430,21 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
     if (c->plan.log_n == 0) {
         if (d_in != d_out) HIPCHK(hipMemcpyAsync(d_out, d_in, batch * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         return 0;
+    }
+    if (lde_log == 0 && lq == 0 && row2048_enabled(c->plan, batch)) {
+        // n = 2^11 in launches of at least TOYNI_R2048_MIN_ROWS transforms: one sweep, one wave per transform
+        hipError_t err = hipSuccess;
+        const bool nt = (uint64_t)batch * n * sizeof(uint32_t) >= nt_min_bytes();
+        const bool ok = row2048_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch, [&](const PassArgs& a, uint64_t rows) {
+            TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, 0);
+            uint64_t grid = (rows + Row2048::WAVES - 1) / Row2048::WAVES;
+            if (grid > (uint64_t)c->num_cus) grid = (uint64_t)c->num_cus;     // one 1024-thread workgroup per CU (132 KiB of LDS + 15 KiB of twiddles)
+            if (nt) hipLaunchKernelGGL((ntt_row2048_kernel<true>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
+            else hipLaunchKernelGGL((ntt_row2048_kernel<false>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
+            err = hipGetLastError();
+        }, cs);
+        if (!ok) return TOYNI_E_INVALID_SIZE;
+        return (int)err;
     }
     if (lde_log == 0 && lq == 0 && lds_kernel_enabled(c->plan, batch)) {
         // n = 2^11 .. 2^15: one sweep, the transform never leaves the workgroup's LDS (no intermediate buffer)
@@ -1629,7 +1698,7 @@ int toyni_ntt_ctx_passes(const toyni_ntt_ctx* c) { return c ? (c->plan.log_n == 
 int toyni_ntt_ctx_passes_for(const toyni_ntt_ctx* c, size_t batch) {
     if (!c) return -1;
     if (c->plan.log_n == 0 || batch == 0) return 0;
-    if (lds_kernel_enabled(c->plan, batch)) return 1;
+    if (row2048_enabled(c->plan, batch) || lds_kernel_enabled(c->plan, batch)) return 1;
     return use_two_pass_plan(c, batch, 0, 0) ? c->plan_lat.npasses : c->plan.npasses;
 }
 
@@ -2070,7 +2139,7 @@ int toyni_ntt_slab_rows_device(toyni_ntt_ctx* big, toyni_ntt_ctx* row, uint32_t*
     {
         TOYNI_CTX_LOCK(row);   // (big is only read: its tables are immutable after creation)
         DeviceGuard guard(row->device);
-        const bool candidate = row->plan.npasses >= 2 && rows_local >= 2 && !lds_kernel_enabled(row->plan, rows_local) &&
+        const bool candidate = row->plan.npasses >= 2 && rows_local >= 2 && !lds_kernel_enabled(row->plan, rows_local) && !row2048_enabled(row->plan, rows_local) &&
                                !(row->chunk_elems && row->chunk_elems / row->n < rows_local);   // (a chunked context keeps its chunks: two-step form)
         if (candidate) {
             SlabIo sio;
