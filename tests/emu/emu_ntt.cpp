@@ -90,6 +90,21 @@ static void emu_transform(const NttPlan& plan, bool inverse, const uint32_t* src
         cs.hi = cblob.data() + hi_off;
     }
     if (plan.log_n == 0 && src != dst) std::memcpy(dst, src, batch * sizeof(uint32_t));
+    if (LQ == 0 && use_row2048 && plan.log_n == 12 && !lde_log) {   // two waves per transform: the pair steps through its row, a barrier between steps
+        bool okr = row2048_transform(plan, blob.data(), inverse, src, dst, batch, [&](const PassArgs& a, uint64_t rows) {
+            using R = Row4096;
+            std::vector<uint32_t> row_lds(R::ROW_WORDS, 0xDEADBEEFu);
+            std::vector<uint32_t> regs(128 * R::E);
+            for (uint64_t row = 0; row < rows; ++row) {
+                for (uint32_t t = 0; t < 128; ++t) R::load_row<false>(a, row, t, *reinterpret_cast<uint32_t (*)[R::E]>(&regs[(size_t)t * R::E]));
+                for (uint32_t t = 0; t < 128; ++t) R::step1(a, t, *reinterpret_cast<uint32_t (*)[R::E]>(&regs[(size_t)t * R::E]), row_lds.data(), R::tw1_global(a));
+                for (uint32_t t = 0; t < 128; ++t) R::step2(t, row_lds.data(), R::tw2_global(a));
+                for (uint32_t t = 0; t < 128; ++t) R::step3<false>(a, R::consts(a), row, t, row_lds.data());
+            }
+        }, cs);
+        CHECK(okr, "row4096 transform rejected log_n=%d", plan.log_n);
+        return;
+    }
     if (LQ == 0 && use_row2048 && plan.log_n == 11 && !lde_log) {   // one wave per transform: stepped wave by wave, lane by lane within a step
         bool okr = row2048_transform(plan, blob.data(), inverse, src, dst, batch, [&](const PassArgs& a, uint64_t rows) {
             using R = Row2048;
@@ -682,14 +697,14 @@ int main(int argc, char** argv) {
     test_field();
     std::printf("field ok=%d\n", failures == 0);
     for (int log_n = 0; log_n <= max_log; ++log_n) {
-        if (log_n == 11) {                          // n = 2^11: the two-pass plan below, and the one-wave-per-transform kernel (ragged batches, coset)
+        if (log_n == 11 || log_n == 12) {           // n = 2^11 / 2^12: the plans below, and the one- / two-waves-per-transform kernels (ragged batches, coset)
             use_row2048 = true;
             test_ntt(log_n, 1, 0);
             test_ntt(log_n, 19, 0);
             test_coset(log_n, 3, 7);
             use_row2048 = false;
         }
-        if (log_n >= 12 && log_n <= 15) {           // these sizes have two executors: first the two-pass plan ...
+        if (log_n >= 13 && log_n <= 15) {           // these sizes have two executors: first the two-pass plan ...
             use_lds = false;
             test_ntt(log_n, 3, 0);
             test_coset(log_n, 2, 7);

@@ -23,7 +23,7 @@ def test_no_kernel_spills_and_occupancy_targets_hold():
     seen = 0
     for b in blocks:
         name = b.split(" ")[0]
-        if not any(k in name for k in ("ntt_pass_kernel", "ntt_lds_kernel", "ntt_pass3_kernel", "ntt_pass3s_kernel", "ntt_row2048_kernel")):
+        if not any(k in name for k in ("ntt_pass_kernel", "ntt_lds_kernel", "ntt_pass3_kernel", "ntt_pass3s_kernel", "ntt_row2048_kernel", "ntt_row4096_kernel")):
             continue
 
         def field(key):
@@ -32,9 +32,7 @@ def test_no_kernel_spills_and_occupancy_targets_hold():
             return int(m.group(1))
 
         seen += 1
-        # known and measured: the 8-row single-sweep shape of n = 2^12 (four columns per thread in phase A) spill 20 B
-        # per lane and are still 2-4 % faster than their spill-free 16-row shapes (profiles/r01_sweep_lds.txt)
-        allowed = 32 if re.search(r"ntt_lds_kernel.*LdsPassILi2ELi3E", name) else 0
+        allowed = 0   # (rounds 1-4 tolerated 20 B of scratch in the 8-row LDS-kernel shapes of n = 2^11 / 2^12: those shapes are gone)
         assert field(r"ScratchSize \[bytes/lane\]") <= allowed, f"{name} spills {field(r'ScratchSize .bytes/lane.')} bytes per lane"
         assert field("VGPRs") <= 128, name
         assert field(r"Occupancy \[waves/SIMD\]") >= 4, name     # 16 waves per CU: what the pipelined kernels are tuned for

@@ -669,14 +669,14 @@ def test_shipped_library_has_no_measurement_hooks(ta):
 
 
 def test_both_executors_of_the_single_sweep_sizes(ta):
-    # n = 2^12 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
-    # batches of 2^12 / 2^13 only; n = 2^11 has the one-wave-per-transform kernel, tests/test_gpu_stream3.py).  Force each one for every size, small ragged batches, in child processes (the knobs are
+    # n = 2^13 .. 2^15 have two executors: the two-pass plan and the single-sweep LDS kernel (by default used for large
+    # batches of 2^13 only; n = 2^11 / 2^12 have the one- / two-waves-per-transform kernels, tests/test_gpu_stream3.py).  Force each one for every size, small ragged batches, in child processes (the knobs are
     # read once per process); which executor ran is read off the launch records (1 launch per transform vs 2).
     code = (
         "import os, numpy as np, oracle, toyni_amd\n"
         "from test_gpu_parity import DevBuf\n"
         "want_launches = int(os.environ['TOYNI_TEST_LAUNCHES'])\n"
-        "for log_n in range(12 if want_launches == 1 else 11, 16):   # (n = 2^11 has no LDS-kernel form since round 5: Row2048)\n"
+        "for log_n in range(13 if want_launches == 1 else 11, 16):   # (n = 2^11 / 2^12 have no LDS-kernel form since round 5: Row2048 / Row4096)\n"
         "    n, batch = 1 << log_n, 5\n"
         "    ctx = toyni_amd.NttContext(n)\n"
         "    x = oracle.splitmix(batch * n, 777 + log_n).astype(np.uint32)\n"
@@ -706,12 +706,12 @@ def test_both_executors_of_the_single_sweep_sizes(ta):
 
 
 def test_large_batches_of_mid_sizes_take_the_single_sweep_kernel(ta):
-    # the default policy: >= 2^25 elements of n = 2^11 .. 2^13 per call -> one launch (counted on the measurement build);
-    # checked against the oracle on sampled rows
+    # the default policy: >= 2^25 elements of n = 2^13 per call -> one launch of the single-sweep LDS kernel (counted on the
+    # measurement build); checked against the oracle on sampled rows
     code = (
         "import numpy as np, oracle, toyni_amd\n"
         "from test_gpu_parity import DevBuf\n"
-        "n, batch = 1 << 12, 1 << 13\n"
+        "n, batch = 1 << 13, 1 << 12\n"
         "x = np.random.default_rng(12).integers(0, oracle.P, size=n * batch, dtype=np.uint32)\n"
         "ctx = toyni_amd.NttContext(n)\n"
         "buf = DevBuf(toyni_amd, x.nbytes)\n"
@@ -721,7 +721,7 @@ def test_large_batches_of_mid_sizes_take_the_single_sweep_kernel(ta):
         "assert ctx.read_timing()['launches']['forward'] == [1, 0]\n"
         "ctx.timing(False)\n"
         "got = buf.download(np.uint32, x.size)\n"
-        "for b in (0, 1, 7, 4095, 4096, batch - 1):\n"
+        "for b in (0, 1, 7, 2047, 2048, batch - 1):\n"
         "    assert (got[b * n:(b + 1) * n] == oracle.ntt(x[b * n:(b + 1) * n].astype(np.uint64))).all(), b\n"
         "ctx.run_device(buf.ptr, buf.ptr, batch, True)\n"
         "ctx.synchronize()\n"

@@ -267,3 +267,37 @@ def test_n2p11_one_wave_per_transform(ta, batch, shift, inverse, inplace):
         want = oracle.domain_ifft(rows[t], shift) if inverse else oracle.domain_fft(rows[t], n, shift)
         assert (y[t * n:(t + 1) * n] == want).all(), f"2^11 x{batch} shift {shift} inverse {inverse}: transform {t}"
     assert _launched(ta, "ntt_row2048_kernel"), "the one-wave-per-transform kernel never ran"
+
+
+@pytest.mark.parametrize("batch,shift,inverse,inplace", [
+    (2048, 1, False, True),       # the smallest batch that takes the kernel (TOYNI_R4096_MIN_ROWS): 256 tiles of eight rows
+    (2051, 7, False, False),      # ragged last tile (three rows of eight): forward coset, out of place
+    (2500, 1234567, True, True),  # inverse coset
+    (2300, 1, True, False),       # plain inverse
+])
+def test_n2p12_two_waves_per_transform(ta, batch, shift, inverse, inplace):
+    """n = 2^12 in ONE sweep, two waves per transform, eight transforms per workgroup (Row4096, ntt_row4096_kernel).  EVERY transform of
+    the batch against the oracle."""
+    n = 1 << 12
+    rng = np.random.default_rng(0x4096 + batch)
+    x = rng.integers(0, P, size=n * batch, dtype=np.uint32)
+    ctx = ta.ntt.get_or_create_ctx(n)
+    assert ctx.passes == 2 and ctx.passes_for(batch) == 1 and ctx.passes_for(5) == 2
+    a = DevBuf(ta, x.nbytes)
+    b = a if inplace else DevBuf(ta, x.nbytes)
+    try:
+        a.upload(x)
+        ctx.run_device(a.ptr, b.ptr, batch, inverse, shift=shift)
+        ctx.synchronize()
+        y = b.download(np.uint32, x.size)
+        if not inplace:
+            assert (a.download(np.uint32, x.size) == x).all(), "out-of-place transform modified its input"
+    finally:
+        a.free()
+        if b is not a:
+            b.free()
+    rows = x.reshape(batch, n).astype(np.uint64)
+    for t in range(batch):
+        want = oracle.domain_ifft(rows[t], shift) if inverse else oracle.domain_fft(rows[t], n, shift)
+        assert (y[t * n:(t + 1) * n] == want).all(), f"2^12 x{batch} shift {shift} inverse {inverse}: transform {t}"
+    assert _launched(ta, "ntt_row4096_kernel"), "the two-waves-per-transform kernel never ran"

@@ -1492,6 +1492,115 @@ struct Row2048 {
     }
 };
 
+// ---- n = 2^12 in ONE sweep, TWO waves per transform (round 5) ------------------------------------------------------------------
+// The same three register steps for a 4096-point row: 128 threads (two waves) per transform, eight transforms per 1024-thread
+// workgroup, contiguous loads and stores.  Two waves share a row, so the steps are separated by workgroup barriers again (an
+// s_barrier cannot name a pair of waves), and the workgroup walks TILES of eight rows in lockstep.
+//   position r = (a << 7) | (b << 3) | d   a: 5 bits (step 1, registers), b: 4 bits (step 2), d: 3 bits (step 3); LDS word r + (r >> 5)
+//     step 1  thread tau = (b, d), registers over a          : words tau + (tau >> 5) + 132 i
+//     step 2  lanes over (a & 7, d & 3), registers over b    : words 132 a + d + 8 b + (b >> 2)        -- bank 4 a + d: 32 different ones
+//     step 3  u = 2 (tau & 63) + (tau >> 6), hm = 4 u + rev2(g), registers over d: words 33 u + 8 rev2(g) + j  -- bank 2 t + w: two-way
+//   output sub-index in step 3: k = rev3(j) << 9 | (g << 7) | (wave of the pair << 6) | rev6(lane): 64 consecutive words per store.
+// The step-1 stages are radix 2 (the radix-4 companion slice would not fit next to eight rows: 151.5 KiB as it is).
+struct Row4096 {
+    static constexpr int LM = 12;
+    static constexpr uint32_t M = 4096, E = 32, ROWS = 8, T = 1024;
+    static constexpr uint32_t ROW_WORDS = M + (M >> 5);
+    static constexpr uint32_t LDS_WORDS = ROWS * ROW_WORDS;
+    static constexpr uint32_t TW1_WORDS = M - 128u;     // stages 7 .. 11 of the packed 4096-point stage table
+    static constexpr uint32_t TW2_WORDS = 120u;         // stages 3 .. 6 (step 2): words [7, 127)
+    using Stg = Pass<KIND_ROW_N, 5, 5, 3>;
+    static TOYNI_HD const uint32_t* tw1_global(const PassArgs& a) { return a.stage_tw + 127u; }
+    static TOYNI_HD const uint32_t* tw2_global(const PassArgs& a) { return a.stage_tw + 7u; }
+    struct Consts { uint32_t uni[4]; };   // w_8^q, wave-uniform (SGPRs)
+    static TOYNI_HD Consts consts(const PassArgs& a) {
+        Consts c{};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) c.uni[q] = TOYNI_UNIFORM(a.stage_tw[3u + q]);
+        return c;
+    }
+    static TOYNI_HD uint32_t kappa_of(uint32_t tau, uint32_t g) { return (g << 7) | ((tau >> 6) << 6) | bitrev32(tau & 63u, 6); }
+    template <bool NT>
+    static TOYNI_HD void load_row(const PassArgs& a, uint64_t row, uint32_t tau, uint32_t (&x)[E]) {
+        const uint32_t* base = a.in + (row << LM);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) x[i] = ld32<NT>(base + i * 128u, tau << 2);
+    }
+    static TOYNI_HD void step1(const PassArgs& a, uint32_t tau, uint32_t (&x)[E], uint32_t* row_lds, const uint32_t* tw1) {
+        if (a.cs_mode == 1u) {   // x[j] *= s^j, j = tau + 128 i
+            uint32_t tw = mont_mul(a.cs_hi[tau >> a.cs_lowbits], a.cs_lo[tau & ((1u << a.cs_lowbits) - 1u)]);
+#pragma unroll
+            for (uint32_t i = 0; i < E; ++i) {
+                x[i] = mont_mul(x[i], tw);
+                if (i + 1 < E) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
+            }
+        }
+        Stg::template stages<5, 7>(x, tw1, tau, nullptr);
+        const uint32_t base = tau + (tau >> 5);
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) row_lds[base + i * 132u] = x[i];
+    }
+    // tw2: words [7, 127) of the packed stage table: entry (1 << (s + 3)) - 8 + d + 8 q = w_{2^(s+4)}^(d + 8 q)
+    static TOYNI_HD void step2(uint32_t tau, uint32_t* row_lds, const uint32_t* tw2) {
+        const uint32_t av = (tau & 7u) | (((tau >> 5) & 3u) << 3);
+#pragma unroll
+        for (uint32_t g = 0; g < 2; ++g) {
+            const uint32_t d = ((tau >> 3) & 3u) | (g << 2);
+            const uint32_t base = 132u * av + d;
+            uint32_t x[16];
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) x[b] = row_lds[base + 8u * b + (b >> 2)];
+#pragma unroll
+            for (int s = 3; s >= 0; --s) {
+                uint32_t tw[8];
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << s); ++q) tw[q] = tw2[(1u << (s + 3)) - 8u + d + (q << 3)];
+#pragma unroll
+                for (uint32_t i = 0; i < 16; ++i) {
+                    if (i & (1u << s)) continue;
+                    const uint32_t w = tw[i & ((1u << s) - 1u)];
+                    const uint32_t u = x[i], v = x[i + (1u << s)];
+                    x[i] = bb_add(u, v);
+                    x[i + (1u << s)] = mont_dot_sub(u, v, w, BB_P - w);
+                }
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) row_lds[base + 8u * b + (b >> 2)] = x[b];
+        }
+    }
+    template <bool NT>
+    static TOYNI_HD void step3(const PassArgs& a, const Consts& c, uint64_t row, uint32_t tau, const uint32_t* row_lds) {
+        uint32_t* out = a.out + (row << LM);
+        const uint32_t u = ((tau & 63u) << 1) | (tau >> 6);
+#pragma unroll
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t base = 33u * u + 8u * cx_bitrev(g, 2);
+            uint32_t x[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) x[j] = row_lds[base + j];
+            Stg::template stages<3, 0>(x, nullptr, 0u, c.uni);
+            const uint32_t kappa = kappa_of(tau, g);
+            const uint32_t off0 = kappa << 2;
+            uint32_t tw = 0u;
+            if (a.cs_mode == 2u) {   // X[k] *= s^k, k = (b << 9) | kappa
+                tw = mont_mul(a.cs_hi[kappa >> a.cs_lowbits], a.cs_lo[kappa & ((1u << a.cs_lowbits) - 1u)]);
+                if (a.scale) tw = mont_mul(tw, a.scale);
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                uint32_t v = x[cx_bitrev(b, 3)];
+                if (a.cs_mode == 2u) {
+                    v = mont_mul(v, tw);
+                    if (b + 1 < 8) { tw = mont_mul_lazy(tw, a.cs_g); TOYNI_PIN(tw); }
+                } else if (a.scale) {
+                    v = mont_mul(v, a.scale);
+                }
+                st32<NT>(out + b * 512u, off0, v);
+            }
+        }
+    }
+};
+
 // ---- u64 <-> u32 edge of the reference-shaped entry points (src/ntt.rs:233: &mut [BabyBear] as *mut u64) ----
 // narrow also reduces mod p, so a non-canonical u64 behaves like BabyBear::new (src/babybear.rs:26-30)
 TOYNI_HD uint32_t narrow_u64(uint64_t v) { return (uint32_t)(v % BB_P); }

@@ -36,10 +36,10 @@ struct NttPlan {
     // compact low levels of its subgroups (SubDomain, ntt_kernels.hpp): dom_sub_off[s] -> w^(x << s), x < 2^(dom_lowbits - s), 0 < s < dom_lowbits
     uint32_t dom_sub_off[32] = {};
     uint32_t scale_inv = 0;             // Montgomery form of n^-1, applied by the first pass of an inverse transform
-    // n = 2^12 .. 2^15: tables of the single-sweep LDS-resident kernel (LdsPass<lds_la>); lds_la = 0 otherwise
+    // n = 2^13 .. 2^15: tables of the single-sweep LDS-resident kernel (LdsPass<lds_la>); lds_la = 0 otherwise
     int lds_la = 0;
     uint32_t lds_stage_a_off = 0, lds_stage_b_off = 0, lds_gtab_off = 0;
-    // n = 2^11: the packed 2048-point stage table and its radix-4 companion (Row2048: one sweep, one wave per transform)
+    // n = 2^11 / 2^12: the packed n-point stage table and its radix-4 companion (Row2048 / Row4096: one sweep, one / two waves per transform)
     uint32_t row_stage_off = 0, row_stage3_off = 0;
     std::vector<uint32_t> fwd, inv;     // table blobs, Montgomery form
 };
@@ -184,7 +184,7 @@ inline bool build_plan(int log_n, NttPlan& plan, bool latency = false) {
             if (dir == 0) { pp.stage_off = stage_off; pp.stage3_off = stage3_off; pp.lo_off = lo_off; pp.hi_off = hi_off; pp.lowbits = lowbits; }
             consumed += pp.log_m;
         }
-        if (log_n >= 12 && log_n <= 15) {   // (n = 2^11 has the one-wave-per-transform kernel instead, round 5: Row2048)
+        if (log_n >= 13 && log_n <= 15) {   // (n = 2^11 / 2^12 have the one- / two-waves-per-transform kernels instead, round 5: Row2048 / Row4096)
             plan.lds_la = log_n - 10;
             plan.lds_stage_a_off = (uint32_t)blob.size();
             append_stage_table(blob, plan.lds_la, bb_pow_host(w, 1ull << 10));            // w_{M_a} = w_n^1024
@@ -194,11 +194,11 @@ inline bool build_plan(int log_n, NttPlan& plan, bool latency = false) {
             uint32_t cur = 1;
             for (uint32_t j = 0; j < 1024; ++j) { blob.push_back(to_mont_host(cur)); cur = bb_mul_host(cur, w); }
         }
-        if (log_n == 11) {
+        if (log_n == 11 || log_n == 12) {
             plan.row_stage_off = (uint32_t)blob.size();
-            append_stage_table(blob, 11, w);
+            append_stage_table(blob, log_n, w);
             plan.row_stage3_off = (uint32_t)blob.size();
-            append_stage3_table(blob, 11, w);
+            append_stage3_table(blob, log_n, w);
         }
         // domain table w_n^(+-x), x < n: the FRI fold reads the inverse one (x_i^-1 = x0^-1 * w_n^-i), the
         // multi-GPU 4-step transform both (same offsets in both blobs)
@@ -581,18 +581,19 @@ inline bool lds_transform(const NttPlan& plan, const uint32_t* tables, bool inve
     const uint64_t per_tile = (1u << log_rows) >> plan.lds_la;
     const uint64_t ntiles = (batch + per_tile - 1) / per_tile;
 #define TOYNI_LDS_CASE(A, B) if (plan.lds_la == A && log_rows == B) { launch(LdsPass<A, B>{}, g, ntiles); return true; }
-    TOYNI_LDS_CASE(2, 5) TOYNI_LDS_CASE(3, 5) TOYNI_LDS_CASE(4, 5) TOYNI_LDS_CASE(5, 5)
-    TOYNI_LDS_CASE(2, 4) TOYNI_LDS_CASE(3, 4) TOYNI_LDS_CASE(4, 4)
-    TOYNI_LDS_CASE(2, 3) TOYNI_LDS_CASE(3, 3)
+    TOYNI_LDS_CASE(3, 5) TOYNI_LDS_CASE(4, 5) TOYNI_LDS_CASE(5, 5)
+    TOYNI_LDS_CASE(3, 4) TOYNI_LDS_CASE(4, 4)
+    TOYNI_LDS_CASE(3, 3)
 #undef TOYNI_LDS_CASE
     return false;
 }
 
-// Arguments of the one-wave-per-transform kernel of n = 2^11 (Row2048, ntt_kernels.hpp).  launch(args, rows).
+// Arguments of the one-wave-per-transform kernel of n = 2^11 (Row2048, ntt_kernels.hpp) and of the two-waves-per-transform kernel of
+// n = 2^12 (Row4096).  launch(args, rows).
 template <class Launch>
 inline bool row2048_transform(const NttPlan& plan, const uint32_t* tables, bool inverse, const uint32_t* src, uint32_t* dst, uint64_t batch,
                               Launch&& launch, const CosetTables& cs = CosetTables()) {
-    if (plan.log_n != 11 || !plan.row_stage3_off) return false;
+    if ((plan.log_n != 11 && plan.log_n != 12) || !plan.row_stage3_off) return false;
     if (batch == 0) return true;
     PassArgs a{};
     a.in = src;
@@ -606,7 +607,8 @@ inline bool row2048_transform(const NttPlan& plan, const uint32_t* tables, bool 
         a.cs_hi = cs.hi;
         a.cs_lowbits = cs.lowbits;
         a.cs_mode = inverse ? 2u : 1u;
-        a.cs_g = to_mont_host(bb_pow_host(cs.s, inverse ? 256ull : 64ull));   // between two stores (k += 256) / two registers of step 1 (j += 64)
+        // between two stores (k += n / 8) / two registers of step 1 (j += n / 32)
+        a.cs_g = to_mont_host(bb_pow_host(cs.s, inverse ? (1ull << (plan.log_n - 3)) : (1ull << (plan.log_n - 5))));
     }
     launch(a, batch);
     return true;

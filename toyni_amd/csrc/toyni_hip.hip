@@ -339,6 +339,56 @@ __global__ void __launch_bounds__(Row2048::T, 4) ntt_row2048_kernel(const PassAr
     }
 }
 
+// n = 2^12 in one sweep, two waves per transform (Row4096): the workgroup walks tiles of eight rows in lockstep (the two waves of a row
+// meet at workgroup barriers); the next tile's loads are issued behind step 1, ahead of this tile's stores.  Rows beyond the batch
+// (a ragged last tile) skip their loads, arithmetic and stores but take part in every barrier.
+template <bool NT>
+__global__ void __launch_bounds__(Row4096::T, 4) ntt_row4096_kernel(const PassArgs a, const uint32_t ntiles) {
+    using R = Row4096;
+    __shared__ uint32_t lds[R::LDS_WORDS + R::TW1_WORDS + R::TW2_WORDS];
+    const uint32_t tid = threadIdx.x, tau = tid & 127u;
+    const uint32_t rho = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 7));
+    uint32_t* lds_tw1 = lds + R::LDS_WORDS;
+    uint32_t* lds_tw2 = lds_tw1 + R::TW1_WORDS;
+    uint32_t* row_lds = lds + rho * R::ROW_WORDS;
+    uint32_t v = blockIdx.x;
+    if (v >= ntiles) return;
+    for (uint32_t j = tid; j < R::TW1_WORDS; j += R::T) lds_tw1[j] = R::tw1_global(a)[j];
+    if (tid < R::TW2_WORDS) lds_tw2[tid] = R::tw2_global(a)[tid];
+    uint32_t x[R::E];
+    uint64_t row = (uint64_t)v * R::ROWS + rho;
+    bool valid = row < a.rows_total;       // wave-uniform
+    if (valid) R::template load_row<NT>(a, row, tau, x);
+    const R::Consts c = R::consts(a);
+    TOYNI_WAIT_VMEM0();
+    __syncthreads();
+    while (true) {
+        TOYNI_WAIT_VMEM_ALLOW(R::E);       // this tile's loads were issued before the previous tile's E stores
+        if (valid) R::step1(a, tau, x, row_lds, lds_tw1);
+        TOYNI_SCHED_FENCE();
+        const uint32_t vn = v + gridDim.x;
+        const bool more = vn < ntiles;     // uniform
+        const uint64_t row_n = (uint64_t)vn * R::ROWS + rho;
+        const bool valid_n = more && row_n < a.rows_total;
+        if (valid_n) R::template load_row<NT>(a, row_n, tau, x);   // prefetch
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        if (valid) R::step2(tau, row_lds, lds_tw2);
+        TOYNI_SCHED_FENCE();
+        TOYNI_LDS_BARRIER();
+        TOYNI_SCHED_FENCE();
+        if (valid) R::template step3<NT>(a, c, row, tau, row_lds);
+        if (!more) break;
+        TOYNI_SCHED_FENCE();
+        TOYNI_BARRIER();                   // the pair's step-3 LDS reads are in registers before the row is overwritten
+        TOYNI_SCHED_FENCE();
+        v = vn;
+        row = row_n;
+        valid = valid_n;
+    }
+}
+
 __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = narrow_u64(in[i]);
@@ -1258,7 +1308,7 @@ int grid_for(size_t items, int block = 256) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// When the single-sweep kernel runs instead of the two-pass plan: sizes 2^11 .. 2^TOYNI_LDS_MAX_LOG (default 13; 10 = never,
+// When the single-sweep kernel runs instead of the two-pass plan: sizes 2^13 .. 2^TOYNI_LDS_MAX_LOG (default 13; 10 = never; 2^11 / 2^12: Row2048 / Row4096 since round 5,
 // 15 = every size it exists for) and launches of at least TOYNI_LDS_MIN_ELEMS elements (default 2^25).  Measured
 // (profiles/r01_sweep_lds.txt): it halves the HBM traffic and is 5-19 % faster on large batches of 2^11 .. 2^13, but the sweep is
 // VALU-bound where the two-pass plan is HBM-bound, so from 2^14 on the two-pass plan wins; and a lone transform is one
@@ -1288,7 +1338,20 @@ uint64_t row2048_min_rows() {
     }();
     return v;
 }
-bool row2048_enabled(const NttPlan& plan, uint64_t batch) { return plan.log_n == 11 && batch >= row2048_min_rows() && batch >= 1; }
+// n = 2^12: the two-waves-per-transform kernel from TOYNI_R4096_MIN_ROWS transforms up (default 2048 -- measured crossover with the
+// two-pass plan: 21.2 against 18.4 us at 1024 rows, 24.1 against 29.6 at 2048, 0.568 against 0.772 ms at 2^16; 0 = always, a huge
+// value = never: the two-pass plan for every batch)
+uint64_t row4096_min_rows() {
+    static const uint64_t v = [] {
+        const char* env = std::getenv("TOYNI_R4096_MIN_ROWS");
+        return env ? (uint64_t)std::strtoull(env, nullptr, 0) : (uint64_t)2048;
+    }();
+    return v;
+}
+bool row2048_enabled(const NttPlan& plan, uint64_t batch) {
+    if (batch < 1) return false;
+    return (plan.log_n == 11 && batch >= row2048_min_rows()) || (plan.log_n == 12 && batch >= row4096_min_rows());
+}
 bool lds_kernel_enabled(const NttPlan& plan, uint64_t batch) {
     return plan.lds_la != 0 && plan.log_n <= lds_max_log() && (batch << plan.log_n) >= lds_min_elems();
 }
@@ -1437,10 +1500,17 @@ int enqueue_transform(toyni_ntt_ctx* c, const uint32_t* d_in, uint32_t* d_out, s
         const bool nt = (uint64_t)batch * n * sizeof(uint32_t) >= nt_min_bytes();
         const bool ok = row2048_transform(c->plan, inverse ? c->d_inv : c->d_fwd, inverse, d_in, d_out, batch, [&](const PassArgs& a, uint64_t rows) {
             TOYNI_PASS_TIMER(c, s, inverse ? 1 : 0, 0);
-            uint64_t grid = (rows + Row2048::WAVES - 1) / Row2048::WAVES;
-            if (grid > (uint64_t)c->num_cus) grid = (uint64_t)c->num_cus;     // one 1024-thread workgroup per CU (132 KiB of LDS + 15 KiB of twiddles)
-            if (nt) hipLaunchKernelGGL((ntt_row2048_kernel<true>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
-            else hipLaunchKernelGGL((ntt_row2048_kernel<false>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
+            if (c->plan.log_n == 11) {
+                uint64_t grid = (rows + Row2048::WAVES - 1) / Row2048::WAVES;
+                if (grid > (uint64_t)c->num_cus) grid = (uint64_t)c->num_cus;     // one 1024-thread workgroup per CU (132 KiB of LDS + 15 KiB of twiddles)
+                if (nt) hipLaunchKernelGGL((ntt_row2048_kernel<true>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
+                else hipLaunchKernelGGL((ntt_row2048_kernel<false>), dim3((unsigned)grid), dim3(Row2048::T), 0, s, a);
+            } else {
+                const uint64_t ntiles = (rows + Row4096::ROWS - 1) / Row4096::ROWS;
+                const uint64_t grid = ntiles < (uint64_t)c->num_cus ? ntiles : (uint64_t)c->num_cus;
+                if (nt) hipLaunchKernelGGL((ntt_row4096_kernel<true>), dim3((unsigned)grid), dim3(Row4096::T), 0, s, a, (uint32_t)ntiles);
+                else hipLaunchKernelGGL((ntt_row4096_kernel<false>), dim3((unsigned)grid), dim3(Row4096::T), 0, s, a, (uint32_t)ntiles);
+            }
             err = hipGetLastError();
         }, cs);
         if (!ok) return TOYNI_E_INVALID_SIZE;
