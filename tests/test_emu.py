@@ -33,7 +33,7 @@ def test_kernel_bodies_match_oracle_on_cpu():
                           # and the interleaved (Ext) form of the streaming closing pass: a lone vector (already 2^7 32-wide tiles' worth),
                           # plain / coset / LDE by 32 and 4 (two vectors, and zero fractions 3 and 4 of the column shape: once by hand,
                           # `emu_ntt 0 Q1 e21x2 l22x3 l22x4`; the GPU tests cover them against the oracle)
-                          "e21", "e22", "Q0"],   # e22: the plain Ext transform keeps three passes; its LDEs take the interleaved 2048-point column shape
+                          "e21", "Q0"],   # (once by hand: `emu_ntt 0 Q1 e22` -- the LDE of Ext vectors to 2^22 through the interleaved 2048-point column shape, 28 s)
                          capture_output=True, text=True, timeout=1800)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert "ALL OK" in res.stdout
